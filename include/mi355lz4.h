@@ -1,0 +1,188 @@
+/*
+ * mi355lz4.h -- C ABI of the MI355X (gfx950) LZ4 block engine.
+ *
+ * This is the drop-in boundary for the hot path of composewell/streamly-lz4:
+ * the two foreign calls made once per block by Streamly.Internal.LZ4,
+ *
+ *   c_compressFastContinue    src/Streamly/Internal/LZ4.hs:123-131 -> cbits/lz4.c:1565
+ *   c_decompressSafeContinue  src/Streamly/Internal/LZ4.hs:133-140 -> cbits/lz4.c:2322
+ *
+ * plus the framing those calls are wrapped in (compressChunk :226-281,
+ * decompressChunk :291-336, header layout :177-207).
+ *
+ * Two faces:
+ *   (1) include/lz4.h  -- the exact 7 legacy symbols the Haskell imports today
+ *       (one block per call; source compatible, not how a GPU should be fed);
+ *   (2) this header    -- the batched ABI (N blocks per call) the modified
+ *       Haskell combinators in INTEGRATION.md bind with `ccall safe`.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return
+ * MI355LZ4_OK (0) or a negative MI355LZ4_E_* code unless stated otherwise.
+ * Every entry point fails with MI355LZ4_E_NO_DEVICE when no gfx950 device is
+ * usable: there is NO CPU fallback.
+ *
+ * Framed block layout (identical to the reference, little-endian int32s):
+ *   headerKind 8 (BlockHasSize, default): [compLen][uncompLen][compLen bytes]
+ *   headerKind 4 (BlockMax64KB..4MB)    : [compLen][compLen bytes]
+ *
+ * Blocks produced by the compressor are INDEPENDENT LZ4 blocks (no reference
+ * into a previous block), which the reference's linked decoder accepts
+ * unchanged.  The decompressor also accepts the reference's LINKED streams:
+ * see mi355lz4_decompress_batch_device (linked != 0).
+ */
+#ifndef MI355LZ4_H
+#define MI355LZ4_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355LZ4_VERSION 100
+
+/* ---- status codes --------------------------------------------------- */
+#define MI355LZ4_OK              0
+#define MI355LZ4_E_NO_DEVICE    (-1)  /* no usable HIP device / not gfx950 */
+#define MI355LZ4_E_HIP          (-2)  /* a HIP runtime call failed (see mi355lz4_last_error) */
+#define MI355LZ4_E_ARG          (-3)  /* bad argument */
+#define MI355LZ4_E_CAPACITY     (-4)  /* output buffer too small */
+#define MI355LZ4_E_BLOCK        (-5)  /* at least one block failed; see per-block status */
+#define MI355LZ4_E_STREAM       (-6)  /* malformed framed stream (header chain) */
+
+/* Per-block decode results follow the reference: >= 0 is the decoded size,
+ * -1 .. -(compLen+1) is cbits/lz4.c:2163's -(ip-src)-1.  Header-level
+ * rejections (what decompressChunk checks at Internal/LZ4.hs:309-318, plus the
+ * short-array case it misses) use this separate range: */
+#define MI355LZ4_BLK_E_COMPLEN   (-0x7F000001)  /* compLen <= 0 or > LZ4_compressBound(LZ4_MAX_INPUT_SIZE) */
+#define MI355LZ4_BLK_E_TRUNCATED (-0x7F000002)  /* header/data runs past the framed buffer */
+#define MI355LZ4_BLK_E_UNCOMPLEN (-0x7F000003)  /* negative uncompLen / exceeds output capacity */
+
+#define MI355LZ4_MAX_INPUT_SIZE 0x7E000000      /* = LZ4_MAX_INPUT_SIZE, cbits/lz4.h:170 */
+
+typedef struct mi355lz4_ctx mi355lz4_ctx;
+
+/* ---- engine lifecycle ------------------------------------------------ */
+int mi355lz4_version(void);
+/* Thread-local description of the last failure in this library. */
+const char *mi355lz4_last_error(void);
+/* Number of usable gfx950 devices (0 when none; never fails). */
+int mi355lz4_device_count(void);
+/* Create an engine bound to HIP device `device` with its own stream. */
+int mi355lz4_create(mi355lz4_ctx **out, int device);
+void mi355lz4_destroy(mi355lz4_ctx *ctx);
+/* Launch on a caller-owned hipStream_t instead (e.g. torch's current stream). */
+int mi355lz4_set_stream(mi355lz4_ctx *ctx, void *hipStream);
+void *mi355lz4_get_stream(mi355lz4_ctx *ctx);
+int mi355lz4_synchronize(mi355lz4_ctx *ctx);
+/* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel,
+ * 2 = lane-parallel kernel.  Tuning/ablation knob; results are identical. */
+int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
+
+/* = LZ4_compressBound (cbits/lz4.c:674, lz4.h:171): n + n/255 + 16, 0 if n too large */
+int mi355lz4_compress_bound(int n);
+/* Bytes one worst-case framed slot needs for a block of blockLen bytes, rounded up to 16. */
+size_t mi355lz4_slot_stride(int blockLen, int headerKind);
+
+/* ---- device-resident batched API (all data pointers are DEVICE pointers;
+ *      asynchronous on the engine's stream) ----------------------------- */
+
+/* Compress nBlocks blocks.  Block i is src[srcOff[i] .. srcOff[i]+srcLen[i]);
+ * srcOff == NULL means srcOff[i] = i * blockStride; srcLen == NULL means every
+ * block is maxBlockLen bytes (maxBlockLen must bound every srcLen[i]: it picks
+ * the hash-table entry width).  Block i's framed bytes
+ * ([header][data]) are written at slots + i*slotStride and their count
+ * (headerKind + compLen) to framedLen[i].  accel follows
+ * LZ4_compress_fast_continue (clamped to [1,65537], cbits/lz4.c:1577-1578).
+ * replaces: compressChunk, Internal/LZ4.hs:226-281. */
+int mi355lz4_compress_batch_device(mi355lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                   const int32_t *srcLen, uint64_t blockStride, int maxBlockLen, int nBlocks,
+                                   int accel, int headerKind, uint8_t *slots, size_t slotStride,
+                                   int32_t *framedLen);
+
+/* Pack slots into one dense framed stream: denseOff[0..nBlocks] receives the
+ * exclusive scan of framedLen (denseOff[nBlocks] = total), dense the bytes. */
+int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slotStride,
+                            const int32_t *framedLen, int nBlocks, uint8_t *dense, size_t denseCap,
+                            uint64_t *denseOff);
+
+/* Decompress nBlocks framed blocks.  Block i's header starts at
+ * framed + blockOff[i]; its output goes to out + outOff[i] with capacity
+ * outCap[i] (outCap == NULL: capacity = header uncompLen, or fixedUncomp for
+ * headerKind 4).  result[i] = decoded size or a negative code (see above).
+ * linked == 0: every block is decoded on its own (LZ4_decompress_safe).
+ * linked != 0: reference stream semantics -- block i may reference the output
+ * of the last block before it that decoded to > 0 bytes, exactly as under
+ * LZ4_decompress_safe_continue with separately allocated blocks
+ * (cbits/lz4.c:2322-2359); blocks must be given in stream order.  Blocks that
+ * decode on their own (everything this engine's compressor emits) still go
+ * through the parallel kernel; only blocks that reach into their predecessor
+ * are re-decoded in stream order.
+ * replaces: decompressChunk, Internal/LZ4.hs:291-336. */
+int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
+                                     const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                                     int linked, uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
+                                     int32_t *result);
+
+/* Read the headers of nBlocks framed blocks at blockOff[] and produce
+ * outOff[0..nBlocks] = exclusive scan of their uncompressed sizes. */
+int mi355lz4_index_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
+                          const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                          uint64_t *outOff);
+
+/* ---- host-buffer batched API (what the Haskell shim binds; synchronous) - */
+
+/* Compress nBlocks host arrays into one dense framed stream in framedOut
+ * (capacity cap).  blockFramedLen[i] (optional) = headerKind + compLen of
+ * block i, so the caller can slice one Array per block like compressChunk does.
+ * status[i] (optional) = compLen > 0, or 0 on failure (reference convention,
+ * Internal/LZ4.hs:257-260). */
+int mi355lz4_compress_batch(mi355lz4_ctx *ctx, const uint8_t *const *src, const int32_t *srcLen,
+                            int nBlocks, int accel, int headerKind, uint8_t *framedOut, size_t cap,
+                            size_t *outLen, int32_t *blockFramedLen, int32_t *status);
+
+/* Walk the header chain of a dense framed stream on the host
+ * (resizeChunksD's job, Internal/LZ4.hs:459-484): fills blockOff[k] and
+ * uncompLen[k] for up to maxBlocks blocks; *nBlocks = blocks found.
+ * MI355LZ4_E_STREAM on a malformed chain (trailing partial block). */
+int mi355lz4_index_host(const uint8_t *framedIn, size_t inLen, int headerKind, int fixedUncomp,
+                        uint64_t *blockOff, int32_t *uncompLen, int maxBlocks, int *nBlocks);
+
+/* Decompress a dense framed stream held in host memory.  Output blocks are
+ * written back to back into out; blockLen[k] = decoded size of block k (>= 0)
+ * or its negative code.  linked as for the device call; when linked, dict /
+ * dictLen (host memory, may be NULL/0) is the output of the block that preceded
+ * framedIn[0] in the stream -- the array the Haskell decoder state keeps alive
+ * (Internal/LZ4.hs:564) -- so a stream can be fed in several calls. */
+int mi355lz4_decompress_batch(mi355lz4_ctx *ctx, const uint8_t *framedIn, size_t inLen, int headerKind,
+                              int fixedUncomp, int linked, const uint8_t *dict, int dictLen, uint8_t *out,
+                              size_t cap, size_t *outLen, int32_t *blockLen, int maxBlocks, int *nBlocks);
+
+/* ---- synthetic inputs (bench / test support; SURVEY.md 8d generators) ---
+ * kind: 0 = xorshift64* random, 1 = lzsynth(litMax, offMax), 2 = text-like.
+ * Block i of the batch is seeded by (firstBlock + i * blockStep); it is written
+ * at dst + i*blockLen.  dst is a device pointer. */
+int mi355lz4_generate_device(mi355lz4_ctx *ctx, int kind, uint8_t *dst, int blockLen, int nBlocks,
+                             uint64_t firstBlock, uint64_t blockStep, uint32_t litMax, uint32_t offMax);
+
+/* ---- ordered multi-GPU gather support -------------------
+ * Scatter rank-local dense blocks into the global stream on the root:
+ * local block j of rank g (nRanks ranks, round-robin) is global block
+ * j*nRanks+g; its bytes local[localOff[j] .. localOff[j+1]) are copied to
+ * global + globalOff[j*nRanks+g].  All pointers are device pointers. */
+int mi355lz4_interleave_device(mi355lz4_ctx *ctx, const uint8_t *local, const uint64_t *localOff,
+                               int nLocalBlocks, int rank, int nRanks, uint8_t *global,
+                               const uint64_t *globalOff);
+
+/* ---- timing support: HIP events on the engine's own stream ------------- */
+int mi355lz4_event_create(void **ev);
+int mi355lz4_event_destroy(void *ev);
+int mi355lz4_event_record(mi355lz4_ctx *ctx, void *ev);
+/* Blocks until `stop` completed; *ms = elapsed milliseconds start -> stop. */
+int mi355lz4_event_elapsed_ms(void *start, void *stop, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355LZ4_H */

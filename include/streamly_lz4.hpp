@@ -1,0 +1,87 @@
+// streamly_lz4.hpp -- C++ host-side mirror of the reference's operator interface
+// for the LZ4 hot path (GHC is not available in the build image, and the
+// reference host code is compiled Haskell, so the mirror above the C ABI is C++).
+//
+// Same names, argument meaning and error behaviour as
+//   Streamly.LZ4                 (reference src/Streamly/LZ4.hs:94-122)
+//   Streamly.Internal.LZ4        (reference src/Streamly/Internal/LZ4.hs:338-651)
+//   Streamly.Internal.LZ4.Config (reference src/Streamly/Internal/LZ4/Config.hs)
+// over a pull stream of byte arrays (the analogue of `SerialT m (Array Word8)`).
+// Errors the reference raises with `error`/`Parser.die` are thrown as
+// streamly_lz4::Error carrying the same message text.
+//
+// All codec arithmetic happens on the GPU through include/mi355lz4.h; the
+// combinators batch `batchBlocks` arrays per call.  There is no CPU codec here.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct mi355lz4_ctx;
+
+namespace streamly_lz4 {
+
+using Array = std::vector<uint8_t>;                     // Array Word8
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// Pull stream: next() fills `out` and returns true (Yield), or returns false (Stop).
+class ArrayStream {
+public:
+    virtual ~ArrayStream() = default;
+    virtual bool next(Array &out) = 0;
+};
+using StreamPtr = std::unique_ptr<ArrayStream>;
+
+StreamPtr fromList(std::vector<Array> arrays);          // Stream.fromList
+std::vector<Array> toList(ArrayStream &s);              // Stream.toList
+
+// ---- Config.hs:109-136 ------------------------------------------------------
+enum class BlockSize { BlockHasSize, BlockMax64KB, BlockMax256KB, BlockMax1MB, BlockMax4MB };
+struct BlockConfig { BlockSize blockSize = BlockSize::BlockHasSize; };
+struct FrameConfig { bool hasEndMark = false; };
+inline BlockConfig defaultBlockConfig() { return BlockConfig{}; }                       // Config.hs:159-160
+inline FrameConfig defaultFrameConfig() { return FrameConfig{}; }                       // Config.hs:100-103
+inline BlockConfig setBlockMaxSize(BlockSize bs, BlockConfig c) { c.blockSize = bs; return c; }   // Config.hs:139-140
+inline FrameConfig setFrameEndMark(bool v, FrameConfig c) { c.hasEndMark = v; return c; }         // Config.hs:78-79
+
+int metaSize(const BlockConfig &c);                     // Internal/LZ4.hs:177-181
+int maxBlockSize(const BlockConfig &c);                 // Internal/LZ4.hs:275-281
+
+// GPU engine handle shared by the combinators.
+class Engine {
+public:
+    explicit Engine(int device = 0, size_t batchBlocks = 4096);
+    ~Engine();
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    mi355lz4_ctx *ctx() const { return ctx_; }
+    size_t batchBlocks() const { return batch_; }
+    void setBatchBlocks(size_t n) { batch_ = n ? n : 1; }
+private:
+    mi355lz4_ctx *ctx_ = nullptr;
+    size_t batch_;
+};
+
+// ---- Streamly.LZ4 / Streamly.Internal.LZ4 -------------------------------------
+// compressChunks cfg speed          (LZ4.hs:94-100, Internal/LZ4.hs:353-394)
+StreamPtr compressChunks(const BlockConfig &cfg, int speed, StreamPtr in, Engine &eng);
+// resizeChunksD cfg conf            (Internal/LZ4.hs:432-523)
+StreamPtr resizeChunks(const BlockConfig &cfg, const FrameConfig &conf, StreamPtr in);
+// decompressChunksRawD cfg          (Internal/LZ4.hs:539-567)
+StreamPtr decompressChunksRaw(const BlockConfig &cfg, StreamPtr in, Engine &eng);
+// decompressChunks cfg = decompressChunksRawD cfg . resizeChunksD cfg defaultFrameConfig  (LZ4.hs:114-122)
+StreamPtr decompressChunks(const BlockConfig &cfg, StreamPtr in, Engine &eng);
+// simpleFrameParserD                (Internal/LZ4.hs:590-651): consumes the 7-byte
+// frame header from the head of the stream; returns the parsed configs and the
+// stream of what follows.
+std::pair<std::pair<BlockConfig, FrameConfig>, StreamPtr> simpleFrameParser(StreamPtr in);
+// decompressChunksWithD simpleFrameParserD  (Internal/LZ4.hs:569-577)
+StreamPtr decompressChunksWith(StreamPtr in, Engine &eng);
+
+} // namespace streamly_lz4

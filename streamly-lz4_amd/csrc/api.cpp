@@ -1,0 +1,629 @@
+// api.cpp -- C ABI of the MI355X LZ4 block engine (include/mi355lz4.h, include/lz4.h).
+//
+// Host-side plumbing only: argument checks, device workspaces, copies and
+// kernel launches.  All arithmetic of the hot path happens in kernels.hip.
+// There is no CPU code path: without a gfx950 device every call fails.
+#include "../../include/mi355lz4.h"
+#include "../../include/lz4.h"
+
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(MI355LZ4_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct mi355lz4_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int decoder = 0;
+    // workspaces of the host-buffer API (grown on demand, reused across calls)
+    DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
+    DevBuf pinIn, pinOut;   // pinned host staging
+};
+
+static int dev_reserve(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+static int pin_reserve(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) { hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    b.cap = want;
+    return 0;
+}
+static void dev_release(DevBuf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+static void pin_release(DevBuf &b) { if (b.p) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+
+static bool device_is_gfx950(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int mi355lz4_version(void) { return MI355LZ4_VERSION; }
+extern "C" const char *mi355lz4_last_error(void) { return g_err; }
+
+extern "C" int mi355lz4_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; d++) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+extern "C" int mi355lz4_create(mi355lz4_ctx **out, int device)
+{
+    if (!out) return fail(MI355LZ4_E_ARG, "mi355lz4_create: null out");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MI355LZ4_E_NO_DEVICE, "mi355lz4: no HIP device visible (this engine has no CPU path)");
+    if (device < 0 || device >= n) return fail(MI355LZ4_E_ARG, "mi355lz4_create: device %d out of range", device);
+    if (!device_is_gfx950(device))
+        return fail(MI355LZ4_E_NO_DEVICE, "mi355lz4: device %d is not gfx950 (MI355X); kernels are gfx950-only", device);
+    mi355lz4_ctx *c = new (std::nothrow) mi355lz4_ctx();
+    if (!c) return fail(MI355LZ4_E_ARG, "out of host memory");
+    c->device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(MI355LZ4_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->ownStream = true;
+    *out = c;
+    return MI355LZ4_OK;
+}
+
+extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch})
+        dev_release(*b);
+    pin_release(c->pinIn);
+    pin_release(c->pinOut);
+    if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mi355lz4_set_stream(mi355lz4_ctx *c, void *s)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (c->ownStream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s;
+    c->ownStream = false;
+    return MI355LZ4_OK;
+}
+extern "C" void *mi355lz4_get_stream(mi355lz4_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355LZ4_OK;
+}
+
+extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
+{
+    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    c->decoder = variant;
+    return MI355LZ4_OK;
+}
+
+extern "C" int mi355lz4_compress_bound(int n)
+{
+    if ((unsigned)n > (unsigned)MI355LZ4_MAX_INPUT_SIZE) return 0;
+    return n + n / 255 + 16;
+}
+
+extern "C" size_t mi355lz4_slot_stride(int blockLen, int headerKind)
+{
+    size_t b = (size_t)mi355lz4_compress_bound(blockLen) + (size_t)headerKind;
+    return (b + 15) & ~(size_t)15;
+}
+
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MI355LZ4_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return MI355LZ4_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident batched API
+// ---------------------------------------------------------------------------
+extern "C" int mi355lz4_compress_batch_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *srcOff,
+                                              const int32_t *srcLen, uint64_t blockStride, int maxBlockLen,
+                                              int nBlocks, int accel, int headerKind, uint8_t *slots,
+                                              size_t slotStride, int32_t *framedLen)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || maxBlockLen < 0 ||
+        (unsigned)maxBlockLen > (unsigned)MI355LZ4_MAX_INPUT_SIZE)
+        return fail(MI355LZ4_E_ARG, "compress_batch_device: bad arguments");
+    if (nBlocks == 0) return MI355LZ4_OK;
+    if (!src && maxBlockLen > 0) return fail(MI355LZ4_E_ARG, "compress_batch_device: null src");
+    if (!slots || !framedLen) return fail(MI355LZ4_E_ARG, "compress_batch_device: null output");
+    if (slotStride < (size_t)mi355lz4_compress_bound(maxBlockLen) + (size_t)headerKind)
+        return fail(MI355LZ4_E_CAPACITY, "compress_batch_device: slotStride %zu < bound", slotStride);
+    if (accel < 1) accel = 1;                 // cbits/lz4.c:1577
+    if (accel > 65537) accel = 65537;         // cbits/lz4.c:1578
+    HIP_TRY(hipSetDevice(c->device));
+    EncodeArgs a;
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.blockStride = blockStride;
+    a.uniformLen = maxBlockLen; a.nBlocks = nBlocks; a.accel = accel; a.headerKind = headerKind;
+    a.slots = slots; a.slotStride = slotStride; a.framedLen = framedLen;
+    launch_encode(a, maxBlockLen > 65536, c->stream);
+    return check_launch("encode launch");
+}
+
+extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, size_t slotStride,
+                                       const int32_t *framedLen, int nBlocks, uint8_t *dense, size_t denseCap,
+                                       uint64_t *denseOff)
+{
+    if (!c || nBlocks < 0 || !denseOff) return fail(MI355LZ4_E_ARG, "compact_device: bad arguments");
+    if (nBlocks > 0 && (!slots || !framedLen || !dense)) return fail(MI355LZ4_E_ARG, "compact_device: null pointer");
+    (void)denseCap; // the caller sizes dense for the worst case (nBlocks * slotStride)
+    HIP_TRY(hipSetDevice(c->device));
+    launch_compact(slots, slotStride, framedLen, nBlocks, dense, denseOff, c->stream);
+    return check_launch("compact launch");
+}
+
+static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
+                         int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
+                         const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
+                         uint32_t dict0Len)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || fixedUncomp < 0)
+        return fail(MI355LZ4_E_ARG, "decompress_batch_device: bad arguments");
+    if (nBlocks == 0) return MI355LZ4_OK;
+    if (!framed || !blockOff || !outOff || !result) return fail(MI355LZ4_E_ARG, "decompress_batch_device: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    DecodeArgs a;
+    a.framed = framed; a.framedLen = framedLen; a.blockOff = blockOff; a.nBlocks = nBlocks;
+    a.headerKind = headerKind; a.fixedUncomp = fixedUncomp; a.linked = linked ? 1 : 0;
+    a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
+    a.dict0 = dict0; a.dict0Len = dict0Len;
+    if (c->decoder != 1)
+        launch_decode_par(a, c->stream);
+    else
+        launch_decode_seq(a, c->stream);
+    if (linked) launch_decode_fixup_linked(a, c->stream);
+    return check_launch("decode launch");
+}
+
+extern "C" int mi355lz4_decompress_batch_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,
+                                                const uint64_t *blockOff, int nBlocks, int headerKind,
+                                                int fixedUncomp, int linked, uint8_t *out, const uint64_t *outOff,
+                                                const int32_t *outCap, int32_t *result)
+{
+    return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, linked, out, outOff,
+                         outCap, result, nullptr, 0);
+}
+
+extern "C" int mi355lz4_index_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,
+                                     const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                                     uint64_t *outOff)
+{
+    if (!c || nBlocks < 0 || !outOff || (headerKind != 4 && headerKind != 8))
+        return fail(MI355LZ4_E_ARG, "index_device: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = dev_reserve(c->scratch, (size_t)(nBlocks + 1) * sizeof(int32_t));
+    if (r) return r;
+    launch_index(framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, (int32_t *)c->scratch.p, outOff,
+                 c->stream);
+    return check_launch("index launch");
+}
+
+extern "C" int mi355lz4_generate_device(mi355lz4_ctx *c, int kind, uint8_t *dst, int blockLen, int nBlocks,
+                                        uint64_t firstBlock, uint64_t blockStep, uint32_t litMax, uint32_t offMax)
+{
+    if (!c || kind < 0 || kind > 2 || blockLen < 0 || nBlocks < 0 || (nBlocks > 0 && blockLen > 0 && !dst))
+        return fail(MI355LZ4_E_ARG, "generate_device: bad arguments");
+    if (kind == 1 && (litMax == 0 || offMax == 0)) return fail(MI355LZ4_E_ARG, "generate_device: litMax/offMax must be > 0");
+    if (nBlocks == 0 || blockLen == 0) return MI355LZ4_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_generate(kind, dst, blockLen, nBlocks, firstBlock, blockStep, litMax, offMax, c->stream);
+    return check_launch("generate launch");
+}
+
+extern "C" int mi355lz4_interleave_device(mi355lz4_ctx *c, const uint8_t *local, const uint64_t *localOff,
+                                          int nLocalBlocks, int rank, int nRanks, uint8_t *global,
+                                          const uint64_t *globalOff)
+{
+    if (!c || nLocalBlocks < 0 || nRanks <= 0 || rank < 0 || rank >= nRanks)
+        return fail(MI355LZ4_E_ARG, "interleave_device: bad arguments");
+    if (nLocalBlocks == 0) return MI355LZ4_OK;
+    if (!local || !localOff || !global || !globalOff) return fail(MI355LZ4_E_ARG, "interleave_device: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    launch_interleave(local, localOff, nLocalBlocks, rank, nRanks, global, globalOff, c->stream);
+    return check_launch("interleave launch");
+}
+
+// ---------------------------------------------------------------------------
+// events (bench.py times kernels on the engine's own stream)
+// ---------------------------------------------------------------------------
+extern "C" int mi355lz4_event_create(void **ev)
+{
+    if (!ev) return fail(MI355LZ4_E_ARG, "null");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (void *)e;
+    return MI355LZ4_OK;
+}
+extern "C" int mi355lz4_event_destroy(void *ev)
+{
+    if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return MI355LZ4_OK;
+}
+extern "C" int mi355lz4_event_record(mi355lz4_ctx *c, void *ev)
+{
+    if (!c || !ev) return fail(MI355LZ4_E_ARG, "null");
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream));
+    return MI355LZ4_OK;
+}
+extern "C" int mi355lz4_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!start || !stop || !ms) return fail(MI355LZ4_E_ARG, "null");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MI355LZ4_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer batched API
+// ---------------------------------------------------------------------------
+static inline int32_t host_le32(const uint8_t *p)
+{
+    return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+}
+
+extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *src, const int32_t *srcLen,
+                                       int nBlocks, int accel, int headerKind, uint8_t *framedOut, size_t cap,
+                                       size_t *outLen, int32_t *blockFramedLen, int32_t *status)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || !outLen)
+        return fail(MI355LZ4_E_ARG, "compress_batch: bad arguments");
+    *outLen = 0;
+    if (nBlocks == 0) return MI355LZ4_OK;
+    if (!src || !srcLen || !framedOut) return fail(MI355LZ4_E_ARG, "compress_batch: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+
+    size_t total = 0;
+    int maxLen = 0;
+    std::vector<uint64_t> offs((size_t)nBlocks);
+    for (int i = 0; i < nBlocks; i++) {
+        // compressChunk's size check, Internal/LZ4.hs:237-241 (BlockHasSize limit = LZ4_MAX_INPUT_SIZE)
+        if (srcLen[i] < 0 || (unsigned)srcLen[i] > (unsigned)MI355LZ4_MAX_INPUT_SIZE)
+            return fail(MI355LZ4_E_ARG, "compress_batch: block %d length %d exceeds the maximum block size", i, srcLen[i]);
+        if (srcLen[i] > 0 && !src[i]) return fail(MI355LZ4_E_ARG, "compress_batch: block %d is null", i);
+        offs[(size_t)i] = total;
+        total += ((size_t)srcLen[i] + 15) & ~(size_t)15;   // 16-aligned block starts
+        if (srcLen[i] > maxLen) maxLen = srcLen[i];
+    }
+    const size_t stride = mi355lz4_slot_stride(maxLen, headerKind);
+    int r;
+    if ((r = pin_reserve(c->pinIn, total + 16))) return r;
+    if ((r = dev_reserve(c->in, total + 16))) return r;
+    if ((r = dev_reserve(c->offA, (size_t)nBlocks * 8))) return r;
+    if ((r = dev_reserve(c->lenA, (size_t)nBlocks * 4))) return r;
+    if ((r = dev_reserve(c->lenB, (size_t)nBlocks * 4))) return r;
+    if ((r = dev_reserve(c->slots, (size_t)nBlocks * stride))) return r;
+    if ((r = dev_reserve(c->dense, (size_t)nBlocks * stride))) return r;
+    if ((r = dev_reserve(c->offB, ((size_t)nBlocks + 1) * 8))) return r;
+
+    uint8_t *stage = (uint8_t *)c->pinIn.p;
+    for (int i = 0; i < nBlocks; i++)
+        if (srcLen[i] > 0) memcpy(stage + offs[(size_t)i], src[i], (size_t)srcLen[i]);
+    HIP_TRY(hipMemcpyAsync(c->in.p, stage, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->offA.p, offs.data(), (size_t)nBlocks * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->lenA.p, srcLen, (size_t)nBlocks * 4, hipMemcpyHostToDevice, c->stream));
+    // offs / srcLen are pageable: make sure the copies have consumed them before they go away
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    r = mi355lz4_compress_batch_device(c, (const uint8_t *)c->in.p, (const uint64_t *)c->offA.p,
+                                       (const int32_t *)c->lenA.p, 0, maxLen, nBlocks, accel, headerKind,
+                                       (uint8_t *)c->slots.p, stride, (int32_t *)c->lenB.p);
+    if (r) return r;
+    r = mi355lz4_compact_device(c, (const uint8_t *)c->slots.p, stride, (const int32_t *)c->lenB.p, nBlocks,
+                                (uint8_t *)c->dense.p, (size_t)nBlocks * stride, (uint64_t *)c->offB.p);
+    if (r) return r;
+
+    std::vector<int32_t> flen((size_t)nBlocks);
+    uint64_t totalOut = 0;
+    HIP_TRY(hipMemcpyAsync(flen.data(), c->lenB.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&totalOut, (const uint8_t *)c->offB.p + (size_t)nBlocks * 8, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    int bad = 0;
+    for (int i = 0; i < nBlocks; i++) {
+        const int32_t f = flen[(size_t)i];
+        if (blockFramedLen) blockFramedLen[i] = f;
+        if (status) status[i] = (f > headerKind) ? f - headerKind : 0;
+        if (f <= headerKind) bad++;
+    }
+    if (bad) return fail(MI355LZ4_E_BLOCK, "compress_batch: %d block(s) failed", bad);
+    if (totalOut > cap) return fail(MI355LZ4_E_CAPACITY, "compress_batch: need %llu bytes, have %zu", (unsigned long long)totalOut, cap);
+    HIP_TRY(hipMemcpyAsync(framedOut, c->dense.p, (size_t)totalOut, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *outLen = (size_t)totalOut;
+    return MI355LZ4_OK;
+}
+
+extern "C" int mi355lz4_index_host(const uint8_t *framedIn, size_t inLen, int headerKind, int fixedUncomp,
+                                   uint64_t *blockOff, int32_t *uncompLen, int maxBlocks, int *nBlocks)
+{
+    if (!nBlocks || (headerKind != 4 && headerKind != 8) || maxBlocks < 0 || (inLen && !framedIn))
+        return fail(MI355LZ4_E_ARG, "index_host: bad arguments");
+    size_t pos = 0;
+    int k = 0;
+    *nBlocks = 0;
+    while (pos < inLen) {
+        if (pos + (size_t)headerKind > inLen)
+            return fail(MI355LZ4_E_STREAM, "index_host: incomplete block header at offset %zu", pos);
+        const int32_t cl = host_le32(framedIn + pos);
+        const int32_t ul = (headerKind == 8) ? host_le32(framedIn + pos + 4) : fixedUncomp;
+        if (cl <= 0) return fail(MI355LZ4_E_STREAM, "index_host: block %d has compressed length %d", k, cl);
+        if (pos + (size_t)headerKind + (size_t)cl > inLen)
+            return fail(MI355LZ4_E_STREAM, "index_host: incomplete block %d (needs %d bytes)", k, cl);
+        if (k >= maxBlocks) return fail(MI355LZ4_E_CAPACITY, "index_host: more than %d blocks", maxBlocks);
+        if (blockOff) blockOff[k] = pos;
+        if (uncompLen) uncompLen[k] = ul;
+        pos += (size_t)headerKind + (size_t)cl;
+        k++;
+    }
+    *nBlocks = k;
+    return MI355LZ4_OK;
+}
+
+extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                         int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
+                                         uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
+                                         int maxBlocks, int *nBlocksOut)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (!outLen || !nBlocksOut || maxBlocks < 0) return fail(MI355LZ4_E_ARG, "decompress_batch: bad arguments");
+    *outLen = 0;
+    *nBlocksOut = 0;
+    std::vector<uint64_t> boff((size_t)maxBlocks + 1);
+    std::vector<int32_t> ulen((size_t)maxBlocks + 1);
+    int n = 0;
+    int r = mi355lz4_index_host(framedIn, inLen, headerKind, fixedUncomp, boff.data(), ulen.data(), maxBlocks, &n);
+    if (r) return r;
+    if (n == 0) return MI355LZ4_OK;
+    HIP_TRY(hipSetDevice(c->device));
+
+    // output layout: blocks back to back at their header (or fixed) capacity
+    std::vector<uint64_t> ooff((size_t)n + 1);
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (ulen[(size_t)i] < 0) return fail(MI355LZ4_E_STREAM, "decompress_batch: block %d has negative size", i);
+        ooff[(size_t)i] = total;
+        total += (uint64_t)ulen[(size_t)i];
+    }
+    ooff[(size_t)n] = total;
+    if ((r = dev_reserve(c->in, inLen + 16))) return r;
+    if ((r = dev_reserve(c->out, (size_t)total + 16))) return r;
+    if ((r = dev_reserve(c->offA, (size_t)n * 8))) return r;
+    if ((r = dev_reserve(c->offB, ((size_t)n + 1) * 8))) return r;
+    if ((r = dev_reserve(c->res, (size_t)n * 4))) return r;
+    // dictionary in force before block 0: only its last 64 KiB can be referenced, and
+    // keeping exactly 64 KiB preserves the reference's "dictSize >= 64 KB => no offset
+    // check" behaviour (cbits/lz4.c:1764)
+    uint32_t dlen = 0;
+    if (linked && dict && dictLen > 0) {
+        dlen = (dictLen > 65536) ? 65536u : (uint32_t)dictLen;
+        if ((r = dev_reserve(c->scratch, 65536 + 16))) return r;
+        HIP_TRY(hipMemcpyAsync(c->scratch.p, dict + (dictLen - (int)dlen), dlen, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->in.p, framedIn, inLen, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->offA.p, boff.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->offB.p, ooff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    r = decode_device(c, (const uint8_t *)c->in.p, inLen, (const uint64_t *)c->offA.p, n, headerKind, fixedUncomp,
+                      linked, (uint8_t *)c->out.p, (const uint64_t *)c->offB.p, nullptr, (int32_t *)c->res.p,
+                      dlen ? (const uint8_t *)c->scratch.p : nullptr, dlen);
+    if (r) return r;
+    std::vector<int32_t> res((size_t)n);
+    HIP_TRY(hipMemcpyAsync(res.data(), c->res.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // pack the decoded blocks back to back (a block may decode to fewer bytes than its capacity)
+    int bad = 0;
+    uint64_t need = 0;
+    for (int i = 0; i < n; i++) {
+        if (blockLen) blockLen[i] = res[(size_t)i];
+        if (res[(size_t)i] < 0) bad++; else need += (uint64_t)res[(size_t)i];
+    }
+    *nBlocksOut = n;
+    if (bad) return fail(MI355LZ4_E_BLOCK, "decompress_batch: %d block(s) failed", bad);
+    if (need > cap) return fail(MI355LZ4_E_CAPACITY, "decompress_batch: need %llu bytes, have %zu", (unsigned long long)need, cap);
+    if (need == total) {
+        HIP_TRY(hipMemcpyAsync(out, c->out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        uint64_t w = 0;
+        for (int i = 0; i < n; i++) {
+            if (res[(size_t)i] > 0)
+                HIP_TRY(hipMemcpyAsync(out + w, (const uint8_t *)c->out.p + ooff[(size_t)i], (size_t)res[(size_t)i],
+                                       hipMemcpyDeviceToHost, c->stream));
+            w += (uint64_t)res[(size_t)i];
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *outLen = (size_t)need;
+    return MI355LZ4_OK;
+}
+
+// ===========================================================================
+// Legacy face: the 7 symbols Streamly.Internal.LZ4 imports today
+// (src/Streamly/Internal/LZ4.hs:105-143).  One block per call: source
+// compatible, correct, and slow by construction (a PCIe round trip per block) --
+// the batched calls above are what INTEGRATION.md binds instead.
+// ===========================================================================
+static std::mutex g_engineMu;
+static mi355lz4_ctx *g_engine = nullptr;
+
+static mi355lz4_ctx *legacy_engine()
+{
+    std::lock_guard<std::mutex> lk(g_engineMu);
+    if (!g_engine) {
+        int dev = 0;
+        if (const char *e = getenv("MI355LZ4_DEVICE")) dev = atoi(e);
+        if (mi355lz4_create(&g_engine, dev) != MI355LZ4_OK) {
+            fprintf(stderr, "mi355lz4: %s\n", g_err);
+            g_engine = nullptr;
+        }
+    }
+    return g_engine;
+}
+
+struct LZ4_stream_u { uint32_t magic; };
+struct LZ4_streamDecode_u {
+    uint32_t magic;
+    void *dictDev;       // last <= 64 KiB of the previous block's output, on the device
+    uint32_t dictLen;
+    void *inDev, *outDev, *metaDev;
+    size_t inCap, outCap;
+};
+
+extern "C" LZ4_stream_t *LZ4_createStream(void)
+{
+    LZ4_stream_u *s = (LZ4_stream_u *)calloc(1, sizeof(LZ4_stream_u));
+    if (s) s->magic = 0x4C5A3443u;
+    return (LZ4_stream_t *)s;
+}
+extern "C" int LZ4_freeStream(LZ4_stream_t *s) { free(s); return 0; }
+
+extern "C" LZ4_streamDecode_t *LZ4_createStreamDecode(void)
+{
+    LZ4_streamDecode_u *s = (LZ4_streamDecode_u *)calloc(1, sizeof(LZ4_streamDecode_u));
+    if (s) s->magic = 0x4C5A3444u;
+    return (LZ4_streamDecode_t *)s;
+}
+extern "C" int LZ4_freeStreamDecode(LZ4_streamDecode_t *p)
+{
+    LZ4_streamDecode_u *s = (LZ4_streamDecode_u *)p;
+    if (!s) return 0;
+    if (s->dictDev) hipFree(s->dictDev);
+    if (s->inDev) hipFree(s->inDev);
+    if (s->outDev) hipFree(s->outDev);
+    if (s->metaDev) hipFree(s->metaDev);
+    free(s);
+    return 0;
+}
+
+extern "C" int LZ4_compressBound(int inputSize) { return mi355lz4_compress_bound(inputSize); }
+
+// Emits an independent block (never references earlier blocks), which the
+// reference's linked decoder accepts.  Returns 0 on failure like the reference.
+extern "C" int LZ4_compress_fast_continue(LZ4_stream_t *streamPtr, const char *src, char *dst, int srcSize,
+                                          int dstCapacity, int acceleration)
+{
+    (void)streamPtr;
+    mi355lz4_ctx *c = legacy_engine();
+    if (!c || srcSize < 0 || dstCapacity <= 0 || !dst) return 0;
+    const uint8_t *srcs[1] = {(const uint8_t *)src};
+    int32_t lens[1] = {srcSize};
+    std::vector<uint8_t> tmp((size_t)mi355lz4_compress_bound(srcSize) + 8);
+    size_t outLen = 0;
+    int32_t st = 0;
+    std::lock_guard<std::mutex> lk(g_engineMu);
+    if (mi355lz4_compress_batch(c, srcs, lens, 1, acceleration, 4, tmp.data(), tmp.size(), &outLen, nullptr, &st) != MI355LZ4_OK)
+        return 0;
+    if (st <= 0 || st > dstCapacity) return 0;   // limitedOutput: cbits/lz4.c:1024-1027
+    memcpy(dst, tmp.data() + 4, (size_t)st);
+    return st;
+}
+
+// Linked semantics of cbits/lz4.c:2322-2359 for separately allocated blocks: the
+// previous block's output is kept on the device as the external dictionary.
+extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *src, char *dst, int srcSize,
+                                            int dstCapacity)
+{
+    LZ4_streamDecode_u *s = (LZ4_streamDecode_u *)p;
+    mi355lz4_ctx *c = legacy_engine();
+    if (!c || !s) return -1;
+    if (!src) return -1;                                          // cbits/lz4.c:1752
+    if (srcSize < 0 || dstCapacity < 0) return -1;
+    std::lock_guard<std::mutex> lk(g_engineMu);
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    const size_t inNeed = (size_t)srcSize + 16, outNeed = (size_t)dstCapacity + 16;
+    if (s->inCap < inNeed) { if (s->inDev) hipFree(s->inDev); s->inDev = nullptr; if (hipMalloc(&s->inDev, inNeed * 2) != hipSuccess) return -1; s->inCap = inNeed * 2; }
+    if (s->outCap < outNeed) { if (s->outDev) hipFree(s->outDev); s->outDev = nullptr; if (hipMalloc(&s->outDev, outNeed * 2) != hipSuccess) return -1; s->outCap = outNeed * 2; }
+    if (!s->metaDev && hipMalloc(&s->metaDev, 64) != hipSuccess) return -1;
+    if (!s->dictDev && hipMalloc(&s->dictDev, 65536) != hipSuccess) return -1;
+
+    // synthesize a one-block headerKind-4 frame around the payload
+    std::vector<uint8_t> framed((size_t)srcSize + 4);
+    framed[0] = (uint8_t)srcSize; framed[1] = (uint8_t)(srcSize >> 8);
+    framed[2] = (uint8_t)(srcSize >> 16); framed[3] = (uint8_t)(srcSize >> 24);
+    if (srcSize) memcpy(framed.data() + 4, src, (size_t)srcSize);
+    uint64_t meta[2] = {0, 0};   // blockOff[0], outOff[0]
+    int32_t res = -1;
+    if (srcSize == 0) return -1;                                   // cbits/lz4.c:1787 (and :1781 for cap==0)
+    if (hipMemcpyAsync(s->inDev, framed.data(), framed.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(s->metaDev, meta, 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    int32_t *resDev = (int32_t *)((uint8_t *)s->metaDev + 32);
+    if (decode_device(c, (const uint8_t *)s->inDev, framed.size(), (const uint64_t *)s->metaDev, 1, 4, dstCapacity, 1,
+                      (uint8_t *)s->outDev, (const uint64_t *)s->metaDev + 1, nullptr, resDev,
+                      s->dictLen ? (const uint8_t *)s->dictDev : nullptr, s->dictLen) != MI355LZ4_OK)
+        return -1;
+    if (hipMemcpyAsync(&res, resDev, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    if (res <= 0) return res;                                      // :2331 / :2353: context unchanged
+    if (hipMemcpyAsync(dst, s->outDev, (size_t)res, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    const uint32_t keep = (res > 65536) ? 65536u : (uint32_t)res;
+    if (hipMemcpyAsync(s->dictDev, (const uint8_t *)s->outDev + ((size_t)res - keep), keep, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    s->dictLen = keep;
+    return res;
+}

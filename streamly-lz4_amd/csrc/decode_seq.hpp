@@ -1,0 +1,175 @@
+// decode_seq.hpp -- sequence-at-a-time LZ4 block decoder, one wavefront per block.
+//
+// Replaces (per block) LZ4_decompress_safe / LZ4_decompress_safe_forceExtDict,
+// i.e. LZ4_decompress_generic (reference cbits/lz4.c:1737-2165) instantiated
+// (endOnInputSize, decode_full_block, noDict|usingExtDict), as reached from
+// LZ4_decompress_safe_continue (cbits/lz4.c:2322-2359).
+//
+// GPU shape: the token chain is wave-uniform (scalar registers, bytes fetched
+// from a 256-byte register window with v_readlane); the 64 lanes move literal
+// and match bytes.  Results, including the negative error codes -(ip-src)-1
+// (cbits/lz4.c:2163), are identical to the reference: the `fast` flag tracks
+// which of the reference's two loops (:1797-1924 fast, :1929-2151 safe) would be
+// running, because they test their error conditions at different points.
+//
+// This decoder is the always-correct baseline: the lane-parallel decoder
+// (decode_par.hpp) hands a block over to it whenever it meets anything unusual.
+#pragma once
+
+#include "lz4_device.hpp"
+
+namespace lz4dev {
+
+// Overlap-safe match copy.  `match` may be negative (source starts in the
+// external dictionary, cbits/lz4.c:1883-1911): byte k of the source is
+// dict[dictLen + match + k] while match + k < 0, dst[match + k] afterwards.
+// offset == 0 yields zero bytes, as v1.9.3 does (cbits/lz4.c:2122-2130).
+__device__ __forceinline__ void wave_copy_match(uint8_t *dst, int op, int match, uint32_t ml,
+                                                uint32_t offset, const uint8_t *dict, uint32_t dictLen)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    wave_fence();
+    if (offset == 0) {
+        for (uint32_t j = lane; j < ml; j += LZ4_WAVE) dst[op + j] = 0;
+    } else if (offset >= LZ4_WAVE) {
+        // chunk c may read what chunk c-1 wrote: stores and loads of one wave stay in order
+        for (uint32_t c = 0; c < ml; c += LZ4_WAVE) {
+            uint32_t j = c + lane;
+            if (j < ml) {
+                int s = match + (int)j;
+                dst[op + j] = (s < 0) ? dict[(int)dictLen + s] : dst[s];
+            }
+            wave_fence();
+        }
+    } else {
+        // short period: every source byte lies in [match, op), complete before this sequence
+        for (uint32_t j = lane; j < ml; j += LZ4_WAVE) {
+            int s = match + (int)(j % offset);
+            dst[op + j] = (s < 0) ? dict[(int)dictLen + s] : dst[s];
+        }
+    }
+    wave_fence();
+}
+
+// Decode one block.  All arguments are wave-uniform.  [bufLo, bufHi) bounds the
+// readable framed buffer (reads outside return 0 instead of faulting).
+__device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                                const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo,
+                                const uint8_t *bufHi)
+{
+    const int iend = srcLen, oend = cap;
+    const bool useDict = (dict != nullptr) && dictLen > 0;
+    const bool checkOffset = dictLen < 65536u;                 // cbits/lz4.c:1764
+    int ip = 0, op = 0;
+    uint32_t token = 0, ll = 0, ml = 0, offset = 0, s = 0;
+    int match = 0;
+    bool fast;
+
+    if (cap == 0) {                                              // :1781-1785
+        InWindow w0; w0.lo = bufLo; w0.hi = bufHi; w0.load(src);
+        return (srcLen == 1 && w0.byte_at(src) == 0) ? 0 : -1;
+    }
+    if (srcLen == 0) return -1;                                  // :1787
+
+    InWindow win;
+    win.lo = bufLo; win.hi = bufHi;
+    win.load(src);
+    auto rd = [&](int pos) -> uint32_t {
+        const uint8_t *p = src + pos;
+        if (!win.covers(p, 1)) win.load(p);
+        return win.byte_at(p);
+    };
+
+    fast = (oend - op) >= 64;                                    // :1791
+
+    for (;;) {
+        token = rd(ip); ip++;
+        ll = token >> 4;
+
+        if (fast) {
+            // ---------------- fast loop, :1797-1924 ----------------
+            if (ll == 15) {
+                if (ip >= iend - 15) goto error;                 // :1809-1810 (initial_error)
+                do { s = rd(ip); ip++; ll += s; } while (s == 255 && ip < iend - 15);
+                if (op + (int)ll > oend - 32 || ip + (int)ll > iend - 32) { fast = false; goto safe_literal_copy; } // :1818
+            } else {
+                if (ip > iend - 17) { fast = false; goto safe_literal_copy; } // :1831
+            }
+            wave_copy_bytes(dst + op, src + ip, ll);
+            ip += (int)ll; op += (int)ll;
+            offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;        // :1844
+            match = op - (int)offset;
+            ml = token & 15;
+            if (ml == 15) {
+                if (checkOffset && match + (int)dictLen < 0) goto error;      // :1853
+                do { s = rd(ip); ip++; ml += s; if (ip >= iend - 4) goto error; } while (s == 255); // :1854-1855
+                ml += LZ4_MINMATCH;
+                if (op + (int)ml >= oend - 64) { fast = false; goto safe_match_copy; } // :1858
+            } else {
+                ml += LZ4_MINMATCH;
+                if (op + (int)ml >= oend - 64) { fast = false; goto safe_match_copy; } // :1863
+            }
+            if (checkOffset && match + (int)dictLen < 0) goto error;          // :1881
+            if (match < 0) {
+                if (!useDict) goto error;
+                if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;       // :1884-1889
+            }
+            wave_copy_match(dst, op, match, ml, offset, dict, dictLen);
+            op += (int)ml;
+            continue;
+        }
+
+        // ---------------- safe loop, :1929-2151 ----------------
+        if (ll != 15 && ip < iend - 16 && op <= oend - 32) {                  // shortcut :1944-1974
+            wave_copy_bytes(dst + op, src + ip, ll);
+            op += (int)ll; ip += (int)ll;
+            ml = token & 15;
+            offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;
+            match = op - (int)offset;
+            if (ml != 15 && offset >= 8 && match >= 0) {                      // :1959-1969
+                wave_copy_match(dst, op, match, ml + LZ4_MINMATCH, offset, dict, dictLen);
+                op += (int)ml + LZ4_MINMATCH;
+                continue;
+            }
+            goto copy_match;                                                  // :1973
+        }
+        if (ll == 15) {
+            if (ip >= iend - 15) goto error;                                  // :1979-1980
+            do { s = rd(ip); ip++; ll += s; } while (s == 255 && ip < iend - 15);
+        }
+    safe_literal_copy:
+        if (op + (int)ll > oend - LZ4_MFLIMIT || ip + (int)ll > iend - (2 + 1 + LZ4_LASTLITERALS)) { // :1991
+            if (ip + (int)ll != iend || op + (int)ll > oend) goto error;      // :2031-2036
+            wave_copy_bytes(dst + op, src + ip, ll);
+            ip += (int)ll; op += (int)ll;
+            break;                                                            // :2046
+        }
+        wave_copy_bytes(dst + op, src + ip, ll);                              // :2050
+        ip += (int)ll; op += (int)ll;
+        offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;                         // :2055
+        match = op - (int)offset;
+        ml = token & 15;
+    copy_match:
+        if (ml == 15) {
+            do { s = rd(ip); ip++; ml += s; if (ip >= iend - 4) goto error; } while (s == 255); // :2064-2065
+        }
+        ml += LZ4_MINMATCH;
+    safe_match_copy:
+        if (checkOffset && match + (int)dictLen < 0) goto error;              // :2073
+        if (match < 0) {
+            if (!useDict) goto error;
+            if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;           // :2076-2079
+        } else if (op + (int)ml > oend - 12) {                                // :2137
+            if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;           // :2139
+        }
+        wave_copy_match(dst, op, match, ml, offset, dict, dictLen);
+        op += (int)ml;
+    }
+    wave_fence();
+    return op;                                                                // :2156
+
+error:
+    return -ip - 1;                                                           // :2163
+}
+
+} // namespace lz4dev

@@ -1,0 +1,56 @@
+// kernels.h -- launch interface between the C-ABI layer (api.cpp) and kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// per-block header rejection codes (mirrors MI355LZ4_BLK_E_* in include/mi355lz4.h)
+#define BLK_E_COMPLEN   (-0x7F000001)
+#define BLK_E_TRUNCATED (-0x7F000002)
+#define BLK_E_UNCOMPLEN (-0x7F000003)
+// LZ4_compressBound(LZ4_MAX_INPUT_SIZE): reference lz4_MAX_OUTPUT_SIZE, Internal/LZ4.hs:145-147
+#define MAX_COMP_LEN 2122219150
+
+struct DecodeArgs {
+    const uint8_t *framed;
+    uint64_t framedLen;
+    const uint64_t *blockOff;
+    int nBlocks;
+    int headerKind;
+    int fixedUncomp;
+    int linked;
+    uint8_t *out;
+    const uint64_t *outOff;
+    const int32_t *outCap;   // may be null
+    int32_t *result;
+    const uint8_t *dict0;    // linked only: dictionary in force before block 0 (may be null)
+    uint32_t dict0Len;
+};
+
+struct EncodeArgs {
+    const uint8_t *src;
+    const uint64_t *srcOff;  // may be null -> blk * blockStride
+    const int32_t *srcLen;   // may be null -> uniformLen
+    uint64_t blockStride;
+    int uniformLen;
+    int nBlocks;
+    int accel;
+    int headerKind;
+    uint8_t *slots;
+    size_t slotStride;
+    int32_t *framedLen;
+};
+
+void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
+void launch_decode_par(const DecodeArgs &a, hipStream_t s);
+void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
+void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
+void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
+                    uint8_t *dense, uint64_t *denseOff, hipStream_t s);
+void launch_interleave(const uint8_t *local, const uint64_t *localOff, int nLocal, int rank, int nRanks,
+                       uint8_t *global, const uint64_t *globalOff, hipStream_t s);
+void launch_index(const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff, int nBlocks,
+                  int headerKind, int fixedUncomp, int32_t *scratchSizes, uint64_t *outOff, hipStream_t s);
+void launch_generate(int kind, uint8_t *dst, int blockLen, int nBlocks, uint64_t firstBlock,
+                     uint64_t blockStep, uint32_t litMax, uint32_t offMax, hipStream_t s);

@@ -1,0 +1,310 @@
+// kernels.hip -- gfx950 kernels of the MI355X LZ4 block engine and their launchers.
+//
+//   K1  k_decode_seq / k_decode_linked   block decode (decode_seq.hpp)
+//   K2  k_encode<TabT>                   block encode (encode_wave.hpp)
+//   K3  k_scan_u64 + k_copy_ragged       size scan + compaction into the framed stream
+//       k_index                          uncompressed-size scan from block headers
+//       k_generate                       synthetic inputs (bench/test support)
+//
+// Everything is HBM/LDS byte work; there is deliberately no MFMA anywhere.
+#include "kernels.h"
+
+#include "decode_seq.hpp"
+#include "encode_wave.hpp"
+
+using namespace lz4dev;
+
+// ---------------------------------------------------------------------------
+// K1: decode
+// ---------------------------------------------------------------------------
+
+// Validate one block header the way decompressChunk does
+// (reference src/Streamly/Internal/LZ4.hs:299-318) -- plus the short-array case
+// it misses.  Returns 0 or a MI355LZ4_BLK_E_* code; fills compLen / cap.
+__device__ __forceinline__ int read_block_header(const DecodeArgs &a, int blk, const uint8_t *&data,
+                                                 int &compLen, int &cap)
+{
+    const uint64_t off = a.blockOff[blk];
+    if (off + (uint64_t)a.headerKind > a.framedLen) return BLK_E_TRUNCATED;
+    const uint8_t *hdr = a.framed + off;
+    compLen = load_le32(hdr);
+    int uncomp = (a.headerKind == 8) ? load_le32(hdr + 4) : a.fixedUncomp;
+    if (compLen <= 0 || compLen > MAX_COMP_LEN) return BLK_E_COMPLEN;
+    if (off + (uint64_t)a.headerKind + (uint64_t)compLen > a.framedLen) return BLK_E_TRUNCATED;
+    if (uncomp < 0) return BLK_E_UNCOMPLEN;
+    cap = uncomp;
+    if (a.outCap) {
+        if (a.headerKind == 8 && uncomp > a.outCap[blk]) return BLK_E_UNCOMPLEN;
+        if (a.headerKind != 8) cap = a.outCap[blk];
+    }
+    data = hdr + a.headerKind;
+    return 0;
+}
+
+// One wavefront per block, 4 blocks per 256-thread workgroup.
+__global__ __launch_bounds__(256) void k_decode_seq(DecodeArgs a)
+{
+    const int blk = uni((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (blk >= a.nBlocks) return;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = read_block_header(a, blk, data, compLen, cap);
+    if (r == 0)
+        r = decode_block_seq(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
+                             a.framed + a.framedLen);
+    if (lane_id() == 0) a.result[blk] = r;
+}
+
+// Linked stream (reference semantics of LZ4_decompress_safe_continue with every
+// block in its own allocation, cbits/lz4.c:2347-2355): block i may reference the
+// output of the last block before it that decoded to > 0 bytes.  A block that
+// decodes standalone never consulted a dictionary, so its standalone result IS
+// its linked result; only blocks whose standalone decode failed are re-decoded
+// here, in stream order, with the dictionary in force.  The chain is serial, so
+// one wavefront walks it.  
+__global__ __launch_bounds__(64) void k_decode_fixup_linked(DecodeArgs a)
+{
+    const uint8_t *dict = a.dict0;
+    uint32_t dictLen = a.dict0 ? a.dict0Len : 0;
+    for (int blk = 0; blk < a.nBlocks; blk++) {
+        int r = uni(a.result[blk]);
+        uint8_t *dst = a.out + a.outOff[blk];
+        if (r < 0 && r > -0x7F000000 && dictLen > 0) {   // codec error (not a header rejection)
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, blk, data, compLen, cap);
+            if (r == 0)
+                r = decode_block_seq(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen);
+            if (lane_id() == 0) a.result[blk] = r;
+        }
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }          // :2331-2333, :2353-2355
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3(1), dim3(64), 0, s, a);
+}
+
+void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    const unsigned grid = (unsigned)((a.nBlocks + 3) / 4);
+    hipLaunchKernelGGL(k_decode_seq, dim3(grid), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------
+// K2: encode
+// ---------------------------------------------------------------------------
+template <typename TabT>
+__global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
+{
+    __shared__ TabT table[4096];
+    const int blk = (int)blockIdx.x;
+    const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
+    const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
+    uint8_t *slot = a.slots + (size_t)blk * a.slotStride;
+    int c = 0;
+    if (n >= 0 && (sizeof(TabT) == 4 || n <= 65536))
+        c = encode_block_wave<TabT>(a.src + off, n, slot + a.headerKind, a.accel, table);
+    if (lane_id() == 0) {
+        store_le32(slot, c);                                   // Internal/LZ4.hs:262
+        if (a.headerKind == 8) store_le32(slot + 4, n);        // Internal/LZ4.hs:261
+        a.framedLen[blk] = (c > 0) ? a.headerKind + c : 0;
+    }
+}
+
+void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    if (wideTable)
+        hipLaunchKernelGGL(k_encode<uint32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_encode<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------
+// K3: scan + ragged copy
+// ---------------------------------------------------------------------------
+
+// Exclusive scan of n int32 sizes into n+1 uint64 offsets; one 1024-thread workgroup.
+// (n is the block count of a batch: at most a few million.)
+__global__ __launch_bounds__(1024) void k_scan_u64(const int32_t *sizes, int n, uint64_t *offs)
+{
+    __shared__ uint64_t part[1024];
+    const int t = (int)threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    uint64_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += (uint64_t)(uint32_t)max(sizes[i], 0);
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint64_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[t] - sum;
+    for (int i = lo; i < hi; i++) { offs[i] = run; run += (uint64_t)(uint32_t)max(sizes[i], 0); }
+    if (t == 1023) offs[n] = part[1023];
+}
+
+// Copy n bytes with a 256-thread workgroup; dst gets 16-byte aligned stores in
+// the body, src is read with (possibly unaligned) 16-byte loads.
+__device__ __forceinline__ void wg_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+    if (head > n) head = n;
+    if (t < head) dst[t] = src[t];
+    const uint64_t body = (n - head) >> 4;
+    uint4 *d16 = (uint4 *)(dst + head);
+    const uint8_t *s16 = src + head;
+    for (uint64_t i = t; i < body; i += T) {
+        uint4 v;
+        __builtin_memcpy(&v, s16 + (i << 4), 16);   // unaligned 16-byte global load
+        d16[i] = v;
+    }
+    const uint64_t done = head + (body << 4);
+    if (done + t < n) dst[done + t] = src[done + t];
+}
+
+__global__ __launch_bounds__(256) void k_copy_slots(const uint8_t *slots, size_t slotStride,
+                                                    const int32_t *framedLen, const uint64_t *denseOff,
+                                                    uint8_t *dense)
+{
+    const int blk = (int)blockIdx.x;
+    const int n = framedLen[blk];
+    if (n > 0) wg_copy_bytes(dense + denseOff[blk], slots + (size_t)blk * slotStride, (uint64_t)n);
+}
+
+void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
+                    uint8_t *dense, uint64_t *denseOff, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, framedLen, nBlocks, denseOff);
+    if (nBlocks > 0)
+        hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)nBlocks), dim3(256), 0, s, slots, slotStride,
+                           framedLen, denseOff, dense);
+}
+
+__global__ __launch_bounds__(256) void k_interleave(const uint8_t *local, const uint64_t *localOff, int rank,
+                                                    int nRanks, uint8_t *global, const uint64_t *globalOff)
+{
+    const int j = (int)blockIdx.x;
+    const uint64_t n = localOff[j + 1] - localOff[j];
+    wg_copy_bytes(global + globalOff[(size_t)j * nRanks + rank], local + localOff[j], n);
+}
+
+void launch_interleave(const uint8_t *local, const uint64_t *localOff, int nLocal, int rank, int nRanks,
+                       uint8_t *global, const uint64_t *globalOff, hipStream_t s)
+{
+    if (nLocal > 0)
+        hipLaunchKernelGGL(k_interleave, dim3((unsigned)nLocal), dim3(256), 0, s, local, localOff, rank,
+                           nRanks, global, globalOff);
+}
+
+// Header gather for the output index: sizes[i] = uncompressed size of block i (0 if unreadable).
+__global__ __launch_bounds__(256) void k_header_sizes(const uint8_t *framed, uint64_t framedLen,
+                                                      const uint64_t *blockOff, int nBlocks, int headerKind,
+                                                      int fixedUncomp, int32_t *sizes)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= nBlocks) return;
+    int u = fixedUncomp;
+    if (headerKind == 8) {
+        const uint64_t off = blockOff[i];
+        u = (off + 8 <= framedLen) ? load_le32(framed + off + 4) : 0;
+    }
+    sizes[i] = max(u, 0);
+}
+
+void launch_index(const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff, int nBlocks,
+                  int headerKind, int fixedUncomp, int32_t *scratchSizes, uint64_t *outOff, hipStream_t s)
+{
+    if (nBlocks > 0)
+        hipLaunchKernelGGL(k_header_sizes, dim3((unsigned)((nBlocks + 255) / 256)), dim3(256), 0, s, framed,
+                           framedLen, blockOff, nBlocks, headerKind, fixedUncomp, scratchSizes);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, scratchSizes, nBlocks, outOff);
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic inputs: xorshift64* seeded per block by splitmix64.
+// One thread per block; setup only, never timed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t xs64(uint64_t &st)
+{
+    uint64_t x = st;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    st = x;
+    return x * 0x2545F4914F6CDD1DULL;
+}
+
+__global__ __launch_bounds__(64) void k_generate(int kind, uint8_t *dst, int blockLen, int nBlocks,
+                                                 uint64_t firstBlock, uint64_t blockStep, uint32_t litMax,
+                                                 uint32_t offMax)
+{
+    const int b = (int)(blockIdx.x * 64u + threadIdx.x);
+    if (b >= nBlocks) return;
+    uint8_t *out = dst + (size_t)b * (size_t)blockLen;
+    const uint64_t index = firstBlock + (uint64_t)b * blockStep;
+    const uint32_t n = (uint32_t)blockLen;
+    if (kind == 0) {
+        uint64_t st = splitmix64(0x9E3779B97F4A7C15ULL ^ index);
+        if (!st) st = 1;
+        for (uint32_t i = 0; i < n;) {
+            uint64_t r = xs64(st);
+            for (int k = 0; k < 8 && i < n; k++, i++) out[i] = (uint8_t)(r >> (8 * k));
+        }
+    } else if (kind == 1) {
+        uint64_t st = splitmix64(0x9E3779B97F4A7C15ULL ^ index);
+        if (!st) st = 1;
+        uint32_t pos = 0;
+        while (pos < n) {
+            uint32_t L = 1 + (uint32_t)(xs64(st) % litMax);
+            for (uint32_t i = 0; i < L && pos < n; i++) out[pos++] = (uint8_t)(32 + xs64(st) % 64);
+            if (pos >= n) break;
+            uint32_t M = 4 + (uint32_t)(xs64(st) % 61);
+            uint32_t lim = (pos < offMax) ? pos : offMax;
+            uint32_t o = 1 + (uint32_t)(xs64(st) % lim);
+            for (uint32_t i = 0; i < M && pos < n; i++, pos++) out[pos] = out[pos - o];
+        }
+    } else {
+        uint64_t st = splitmix64(0x9E3779B97F4A7C15ULL ^ (index ^ 0x7465787400000000ULL));
+        if (!st) st = 1;
+        uint32_t pos = 0;
+        while (pos < n) {
+            uint64_t r = xs64(st);
+            uint32_t a = (uint32_t)(r & 4095), bq = (uint32_t)((r >> 12) & 4095);
+            uint32_t c = (uint32_t)((r >> 29) & 4095), d = (uint32_t)((r >> 41) & 4095);
+            uint32_t w = (((a * bq) >> 12) * ((c * d) >> 12)) >> 12;
+            uint64_t h = splitmix64(0x776F7264ULL + w);
+            uint32_t len = 2 + (uint32_t)(h & 7);
+            uint32_t sep = (uint32_t)((r >> 24) & 31);
+            for (uint32_t j = 0; j < len && pos < n; j++)
+                out[pos++] = (uint8_t)('a' + ((h >> (3 + 5 * j)) & 31) % 26);
+            if (pos < n) out[pos++] = (sep == 0) ? '\n' : (sep == 1) ? ',' : ' ';
+            if (sep == 1 && pos < n) out[pos++] = ' ';
+        }
+    }
+}
+
+void launch_generate(int kind, uint8_t *dst, int blockLen, int nBlocks, uint64_t firstBlock,
+                     uint64_t blockStep, uint32_t litMax, uint32_t offMax, hipStream_t s)
+{
+    if (nBlocks > 0)
+        hipLaunchKernelGGL(k_generate, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, kind, dst,
+                           blockLen, nBlocks, firstBlock, blockStep, litMax, offMax);
+}
+
+// Lane-parallel decoder entry (decode_par.hpp); until it lands every block takes the
+// sequence-at-a-time kernel.
+void launch_decode_par(const DecodeArgs &a, hipStream_t s) { launch_decode_seq(a, s); }

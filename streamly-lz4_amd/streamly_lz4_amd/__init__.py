@@ -1,0 +1,404 @@
+"""streamly_lz4_amd -- Python binding of the MI355X LZ4 block engine.
+
+Thin ctypes layer over the C ABI in ``include/mi355lz4.h`` (device-resident and
+host-buffer batched calls) and over the C++ mirror of the reference's stream
+combinators (``include/streamly_lz4.hpp``: compressChunks / decompressChunks /
+resizeChunks / decompressChunksWith; reference src/Streamly/LZ4.hs:94-122,
+src/Streamly/Internal/LZ4.hs:338-651).
+
+There is no CPU codec in this package: if ``libmi355lz4.so`` is missing, or no
+gfx950 device is visible, every codec call raises.  PyTorch is used only by
+callers that want device memory / streams / torch.distributed; this module
+itself needs only ctypes and numpy.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = [
+    "lib", "lib_path", "Engine", "LZ4Error", "BlockSize", "BlockConfig", "FrameConfig",
+    "defaultBlockConfig", "defaultFrameConfig", "setBlockMaxSize", "setFrameEndMark",
+    "compressChunks", "decompressChunks", "decompressChunksRaw", "resizeChunks",
+    "decompressChunksWith", "simpleFrameParser", "compress_bound", "slot_stride", "device_count",
+]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmi355lz4.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+
+
+class LZ4Error(RuntimeError):
+    """Raised where the reference calls `error` / `Parser.die`, with the same message."""
+
+
+def _load():
+    if not os.path.exists(lib_path):
+        raise ImportError(
+            "streamly_lz4_amd: %s is missing -- build it with `make lib` (hipcc, gfx950). "
+            "There is no CPU fallback." % lib_path
+        )
+    L = C.CDLL(lib_path, mode=os.RTLD_LOCAL)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    vp = C.c_void_p
+    sig("mi355lz4_version", C.c_int)
+    sig("mi355lz4_last_error", C.c_char_p)
+    sig("mi355lz4_device_count", C.c_int)
+    sig("mi355lz4_create", C.c_int, C.POINTER(vp), C.c_int)
+    sig("mi355lz4_destroy", None, vp)
+    sig("mi355lz4_set_stream", C.c_int, vp, vp)
+    sig("mi355lz4_get_stream", vp, vp)
+    sig("mi355lz4_synchronize", C.c_int, vp)
+    sig("mi355lz4_set_decoder", C.c_int, vp, C.c_int)
+    sig("mi355lz4_compress_bound", C.c_int, C.c_int)
+    sig("mi355lz4_slot_stride", C.c_size_t, C.c_int, C.c_int)
+    sig("mi355lz4_compress_batch_device", C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+        vp, C.c_size_t, vp)
+    sig("mi355lz4_compact_device", C.c_int, vp, vp, C.c_size_t, vp, C.c_int, vp, C.c_size_t, vp)
+    sig("mi355lz4_decompress_batch_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+        vp, vp, vp, vp)
+    sig("mi355lz4_index_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp)
+    sig("mi355lz4_compress_batch", C.c_int, vp, C.POINTER(_u8p), _i32p, C.c_int, C.c_int, C.c_int, _u8p,
+        C.c_size_t, C.POINTER(C.c_size_t), _i32p, _i32p)
+    sig("mi355lz4_index_host", C.c_int, _u8p, C.c_size_t, C.c_int, C.c_int, _u64p, _i32p, C.c_int,
+        C.POINTER(C.c_int))
+    sig("mi355lz4_decompress_batch", C.c_int, vp, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _u8p, C.c_int,
+        _u8p, C.c_size_t, C.POINTER(C.c_size_t), _i32p, C.c_int, C.POINTER(C.c_int))
+    sig("mi355lz4_generate_device", C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+        C.c_uint32, C.c_uint32)
+    sig("mi355lz4_interleave_device", C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp)
+    sig("mi355lz4_event_create", C.c_int, C.POINTER(vp))
+    sig("mi355lz4_event_destroy", C.c_int, vp)
+    sig("mi355lz4_event_record", C.c_int, vp, vp)
+    sig("mi355lz4_event_elapsed_ms", C.c_int, vp, vp, C.POINTER(C.c_float))
+    # legacy face (include/lz4.h)
+    sig("LZ4_createStream", vp)
+    sig("LZ4_freeStream", C.c_int, vp)
+    sig("LZ4_createStreamDecode", vp)
+    sig("LZ4_freeStreamDecode", C.c_int, vp)
+    sig("LZ4_compressBound", C.c_int, C.c_int)
+    sig("LZ4_compress_fast_continue", C.c_int, vp, _u8p, _u8p, C.c_int, C.c_int, C.c_int)
+    sig("LZ4_decompress_safe_continue", C.c_int, vp, _u8p, _u8p, C.c_int, C.c_int)
+    # stream-combinator mirror
+    sig("slz4_last_error", C.c_char_p)
+    sig("slz4_engine_create", C.c_int, C.POINTER(vp), C.c_int, C.c_size_t)
+    sig("slz4_engine_destroy", None, vp)
+    sig("slz4_engine_set_batch", None, vp, C.c_size_t)
+    sig("slz4_engine_ctx", vp, vp)
+    sig("slz4_arrays_count", C.c_size_t, vp)
+    sig("slz4_arrays_len", C.c_size_t, vp, C.c_size_t)
+    sig("slz4_arrays_data", _u8p, vp, C.c_size_t)
+    sig("slz4_arrays_free", None, vp)
+    sig("slz4_compress_chunks", C.c_int, vp, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_resize_chunks", C.c_int, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_decompress_chunks_raw", C.c_int, vp, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_decompress_chunks", C.c_int, vp, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_decompress_chunks_with", C.c_int, vp, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_simple_frame_parser", C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(vp))
+    return L
+
+
+lib = _load()
+
+# every symbol include/mi355lz4.h and include/lz4.h declare (checked by tests without a GPU)
+DECLARED_SYMBOLS = [
+    "mi355lz4_version", "mi355lz4_last_error", "mi355lz4_device_count", "mi355lz4_create", "mi355lz4_destroy",
+    "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder",
+    "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
+    "mi355lz4_decompress_batch_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
+    "mi355lz4_decompress_batch", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
+    "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
+    "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
+    "LZ4_compress_fast_continue", "LZ4_decompress_safe_continue",
+]
+
+
+def _err():
+    return (lib.mi355lz4_last_error() or b"").decode("utf-8", "replace")
+
+
+def _check(rc, what=""):
+    if rc != 0:
+        raise LZ4Error("%s failed (%d): %s" % (what or "mi355lz4 call", rc, _err()))
+
+
+def compress_bound(n):
+    return lib.mi355lz4_compress_bound(int(n))
+
+
+def slot_stride(block_len, header_kind=8):
+    return lib.mi355lz4_slot_stride(int(block_len), int(header_kind))
+
+
+def device_count():
+    return lib.mi355lz4_device_count()
+
+
+# ---------------------------------------------------------------------------
+# Config mirror (reference src/Streamly/Internal/LZ4/Config.hs)
+# ---------------------------------------------------------------------------
+class BlockSize:
+    BlockHasSize = 0
+    BlockMax64KB = 1
+    BlockMax256KB = 2
+    BlockMax1MB = 3
+    BlockMax4MB = 4
+
+
+class BlockConfig:
+    def __init__(self, blockSize=BlockSize.BlockHasSize):
+        self.blockSize = blockSize
+
+    @property
+    def metaSize(self):  # Internal/LZ4.hs:177-181
+        return 8 if self.blockSize == BlockSize.BlockHasSize else 4
+
+    @property
+    def fixedUncomp(self):  # Internal/LZ4.hs:189-198
+        return {0: 0, 1: 64 << 10, 2: 256 << 10, 3: 1 << 20, 4: 4 << 20}[self.blockSize]
+
+
+class FrameConfig:
+    def __init__(self, hasEndMark=False):
+        self.hasEndMark = hasEndMark
+
+
+defaultBlockConfig = BlockConfig()
+defaultFrameConfig = FrameConfig()
+
+
+def setBlockMaxSize(bs, cfg):
+    return BlockConfig(bs)
+
+
+def setFrameEndMark(v, cfg):
+    return FrameConfig(bool(v))
+
+
+# ---------------------------------------------------------------------------
+# Engine
+# ---------------------------------------------------------------------------
+def _dptr(x):
+    """Device pointer of a torch tensor / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib.mi355lz4_event_create(C.byref(self.h)), "event_create")
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.mi355lz4_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Engine:
+    """One GPU engine (HIP device + stream).  Wraps mi355lz4_ctx and the C++ stream-combinator engine."""
+
+    def __init__(self, device=0, batch_blocks=4096):
+        self._h = C.c_void_p()
+        if lib.slz4_engine_create(C.byref(self._h), int(device), int(batch_blocks)) != 0:
+            raise LZ4Error((lib.slz4_last_error() or b"").decode())
+        self.ctx = C.c_void_p(lib.slz4_engine_ctx(self._h))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.slz4_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_batch_blocks(self, n):
+        lib.slz4_engine_set_batch(self._h, int(n))
+
+    def set_decoder(self, variant):
+        _check(lib.mi355lz4_set_decoder(self.ctx, int(variant)), "set_decoder")
+
+    def use_stream(self, hip_stream):
+        _check(lib.mi355lz4_set_stream(self.ctx, C.c_void_p(hip_stream)), "set_stream")
+
+    def synchronize(self):
+        _check(lib.mi355lz4_synchronize(self.ctx), "synchronize")
+
+    # ---- timing on the engine's own stream ---------------------------------
+    def record(self, ev):
+        _check(lib.mi355lz4_event_record(self.ctx, ev.h), "event_record")
+
+    @staticmethod
+    def elapsed_ms(start, stop):
+        ms = C.c_float()
+        _check(lib.mi355lz4_event_elapsed_ms(start.h, stop.h, C.byref(ms)), "event_elapsed")
+        return ms.value
+
+    # ---- device-resident batched API (torch uint8/int32/int64 CUDA tensors) ----
+    def generate(self, kind, dst, block_len, n_blocks, first_block=0, block_step=1, lit_max=16, off_max=2048):
+        k = {"random": 0, "lzsynth": 1, "text": 2}[kind]
+        _check(lib.mi355lz4_generate_device(self.ctx, k, _dptr(dst), int(block_len), int(n_blocks), int(first_block),
+                                            int(block_step), int(lit_max), int(off_max)), "generate_device")
+
+    def compress_batch_device(self, src, n_blocks, max_block_len, slots, slot_stride_, framed_len, accel=1,
+                              header_kind=8, src_off=None, src_len=None, block_stride=None):
+        _check(lib.mi355lz4_compress_batch_device(
+            self.ctx, _dptr(src), _dptr(src_off), _dptr(src_len),
+            int(max_block_len if block_stride is None else block_stride), int(max_block_len), int(n_blocks),
+            int(accel), int(header_kind), _dptr(slots), int(slot_stride_), _dptr(framed_len)), "compress_batch_device")
+
+    def compact_device(self, slots, slot_stride_, framed_len, n_blocks, dense, dense_cap, dense_off):
+        _check(lib.mi355lz4_compact_device(self.ctx, _dptr(slots), int(slot_stride_), _dptr(framed_len), int(n_blocks),
+                                           _dptr(dense), int(dense_cap), _dptr(dense_off)), "compact_device")
+
+    def decompress_batch_device(self, framed, framed_len, block_off, n_blocks, out, out_off, result, header_kind=8,
+                                fixed_uncomp=0, linked=False, out_cap=None):
+        _check(lib.mi355lz4_decompress_batch_device(
+            self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
+            int(fixed_uncomp), int(bool(linked)), _dptr(out), _dptr(out_off), _dptr(out_cap), _dptr(result)),
+            "decompress_batch_device")
+
+    def index_device(self, framed, framed_len, block_off, n_blocks, out_off, header_kind=8, fixed_uncomp=0):
+        _check(lib.mi355lz4_index_device(self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks),
+                                         int(header_kind), int(fixed_uncomp), _dptr(out_off)), "index_device")
+
+    def interleave_device(self, local, local_off, n_local, rank, n_ranks, global_buf, global_off):
+        _check(lib.mi355lz4_interleave_device(self.ctx, _dptr(local), _dptr(local_off), int(n_local), int(rank),
+                                              int(n_ranks), _dptr(global_buf), _dptr(global_off)), "interleave_device")
+
+    # ---- host-buffer batched API -------------------------------------------
+    def compress_batch(self, blocks, accel=1, header_kind=8):
+        """blocks: list of bytes-like.  Returns (framed bytes, [framed length per block])."""
+        n = len(blocks)
+        arrs = [np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b for b in blocks]
+        ptrs = (_u8p * max(n, 1))(*[a.ctypes.data_as(_u8p) for a in arrs])
+        lens = np.array([a.size for a in arrs], dtype=np.int32)
+        cap = int(sum(compress_bound(int(x)) + header_kind for x in lens)) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_size_t()
+        flen = np.zeros(max(n, 1), dtype=np.int32)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        _check(lib.mi355lz4_compress_batch(self.ctx, ptrs, lens.ctypes.data_as(_i32p), n, int(accel), int(header_kind),
+                                           out.ctypes.data_as(_u8p), cap, C.byref(out_len),
+                                           flen.ctypes.data_as(_i32p), status.ctypes.data_as(_i32p)), "compress_batch")
+        return out[: out_len.value].tobytes(), flen[:n].tolist()
+
+    def decompress_batch(self, framed, header_kind=8, fixed_uncomp=0, linked=False, dict_bytes=None, max_blocks=None,
+                         raise_on_block_error=True):
+        """Returns (decoded bytes, [decoded length or negative code per block])."""
+        src = np.frombuffer(bytes(framed), dtype=np.uint8)
+        if max_blocks is None:
+            max_blocks = src.size // (header_kind + 1) + 1
+        boff = np.zeros(max_blocks + 1, dtype=np.uint64)
+        ulen = np.zeros(max_blocks + 1, dtype=np.int32)
+        nb = C.c_int()
+        _check(lib.mi355lz4_index_host(src.ctypes.data_as(_u8p), src.size, header_kind, fixed_uncomp,
+                                       boff.ctypes.data_as(_u64p), ulen.ctypes.data_as(_i32p), max_blocks, C.byref(nb)),
+               "index_host")
+        cap = int(ulen[: nb.value].astype(np.int64).clip(min=0).sum()) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_size_t()
+        blen = np.zeros(max(nb.value, 1), dtype=np.int32)
+        got = C.c_int()
+        d = np.frombuffer(bytes(dict_bytes), dtype=np.uint8) if dict_bytes else None
+        rc = lib.mi355lz4_decompress_batch(self.ctx, src.ctypes.data_as(_u8p), src.size, header_kind, fixed_uncomp,
+                                           int(bool(linked)), d.ctypes.data_as(_u8p) if d is not None else None,
+                                           d.size if d is not None else 0, out.ctypes.data_as(_u8p), cap,
+                                           C.byref(out_len), blen.ctypes.data_as(_i32p), max(nb.value, 1), C.byref(got))
+        if rc != 0 and (raise_on_block_error or rc != -5):
+            _check(rc, "decompress_batch")
+        return out[: out_len.value].tobytes(), blen[: got.value].tolist()
+
+
+# ---------------------------------------------------------------------------
+# Stream-combinator mirror (lists / iterables of bytes in, list of bytes out)
+# ---------------------------------------------------------------------------
+def _pack(arrays):
+    arrays = [bytes(a) for a in arrays]
+    data = np.frombuffer(b"".join(arrays), dtype=np.uint8) if arrays else np.zeros(0, dtype=np.uint8)
+    if data.size == 0:
+        data = np.zeros(1, dtype=np.uint8)
+    lens = np.array([len(a) for a in arrays] + [0], dtype=np.uint64)
+    return data, lens, len(arrays)
+
+
+def _unpack(h):
+    try:
+        n = lib.slz4_arrays_count(h)
+        out = []
+        for i in range(n):
+            ln = lib.slz4_arrays_len(h, i)
+            out.append(C.string_at(lib.slz4_arrays_data(h, i), ln) if ln else b"")
+        return out
+    finally:
+        lib.slz4_arrays_free(h)
+
+
+def _run(fn, *args):
+    h = C.c_void_p()
+    rc = fn(*args, C.byref(h))
+    if rc != 0:
+        raise LZ4Error((lib.slz4_last_error() or b"").decode("utf-8", "replace"))
+    return _unpack(h)
+
+
+def compressChunks(cfg, speed, arrays, engine):
+    """Streamly.LZ4.compressChunks (reference src/Streamly/LZ4.hs:94-100)."""
+    data, lens, n = _pack(arrays)
+    return _run(lib.slz4_compress_chunks, engine._h, cfg.blockSize, int(speed), data.ctypes.data_as(_u8p),
+                lens.ctypes.data_as(_u64p), n)
+
+
+def resizeChunks(cfg, conf, arrays):
+    """Streamly.Internal.LZ4.resizeChunksD (reference src/Streamly/Internal/LZ4.hs:432-523).  Host only."""
+    data, lens, n = _pack(arrays)
+    return _run(lib.slz4_resize_chunks, cfg.blockSize, int(conf.hasEndMark), data.ctypes.data_as(_u8p),
+                lens.ctypes.data_as(_u64p), n)
+
+
+def decompressChunksRaw(cfg, arrays, engine):
+    """Streamly.Internal.LZ4.decompressChunksRawD (reference src/Streamly/Internal/LZ4.hs:539-567)."""
+    data, lens, n = _pack(arrays)
+    return _run(lib.slz4_decompress_chunks_raw, engine._h, cfg.blockSize, data.ctypes.data_as(_u8p),
+                lens.ctypes.data_as(_u64p), n)
+
+
+def decompressChunks(cfg, arrays, engine, conf=defaultFrameConfig):
+    """Streamly.LZ4.decompressChunks (reference src/Streamly/LZ4.hs:114-122); conf selects the end-mark variant."""
+    data, lens, n = _pack(arrays)
+    return _run(lib.slz4_decompress_chunks, engine._h, cfg.blockSize, int(conf.hasEndMark), data.ctypes.data_as(_u8p),
+                lens.ctypes.data_as(_u64p), n)
+
+
+def decompressChunksWith(arrays, engine):
+    """decompressChunksWithD simpleFrameParserD (reference src/Streamly/Internal/LZ4.hs:569-577)."""
+    data, lens, n = _pack(arrays)
+    return _run(lib.slz4_decompress_chunks_with, engine._h, data.ctypes.data_as(_u8p), lens.ctypes.data_as(_u64p), n)
+
+
+def simpleFrameParser(arrays):
+    """simpleFrameParserD (reference src/Streamly/Internal/LZ4.hs:590-651).  Returns ((BlockConfig, FrameConfig), rest)."""
+    data, lens, n = _pack(arrays)
+    h = C.c_void_p()
+    em = C.c_int()
+    kind = lib.slz4_simple_frame_parser(data.ctypes.data_as(_u8p), lens.ctypes.data_as(_u64p), n, C.byref(em), C.byref(h))
+    if kind < 0:
+        raise LZ4Error((lib.slz4_last_error() or b"").decode("utf-8", "replace"))
+    return (BlockConfig(kind), FrameConfig(bool(em.value))), _unpack(h)
