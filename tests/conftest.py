@@ -1,0 +1,57 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The real reference codec; only present where oracle/_ref was built."""
+    from oracle.oracle import Reference, have_reference
+    if not have_reference():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def linked_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "linked_stream.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def slz4():
+    """The product binding.  Import fails loudly when libmi355lz4.so is missing."""
+    import streamly_lz4_amd
+    return streamly_lz4_amd
+
+
+@pytest.fixture(scope="session")
+def engine(slz4):
+    """GPU engine: only requested by gpu-marked tests.  No fallback: creation must succeed."""
+    eng = slz4.Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,155 @@
+"""CPU: host-side logic of the product (no GPU compute): the C-ABI library loads and exports every
+declared symbol, fails loudly without a device, and the C++ stream-combinator mirror's host state
+machines (resizeChunks, simpleFrameParser, header-chain indexing) behave like the reference
+(src/Streamly/Internal/LZ4.hs:432-523, 590-651) -- checked against oracle/framing.py."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from oracle import framing
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(slz4):
+    decl = set()
+    for hdr in ("mi355lz4.h", "lz4.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        decl |= set(re.findall(r"\b((?:mi355lz4|LZ4)_[A-Za-z0-9_]+)\s*\(", text))
+    decl -= {"LZ4_COMPRESSBOUND"}
+    assert decl == set(slz4.DECLARED_SYMBOLS), decl ^ set(slz4.DECLARED_SYMBOLS)
+    for name in decl:
+        assert hasattr(slz4.lib, name), name
+    assert slz4.lib.mi355lz4_version() == 100
+
+
+def test_bound_and_stride(slz4, oracle):
+    for n in (0, 1, 255, 65536, 262144, 0x7E000000):
+        assert slz4.compress_bound(n) == oracle.compress_bound(n) == slz4.lib.LZ4_compressBound(n)
+    assert slz4.compress_bound(0x7E000001) == 0
+    assert slz4.slot_stride(65536, 8) == 65824 and slz4.slot_stride(65536, 8) % 16 == 0
+
+
+def test_no_cpu_fallback(slz4):
+    """Without a gfx950 device the engine must refuse to exist (the product has no CPU codec)."""
+    if slz4.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(slz4.LZ4Error, match="no HIP device|not gfx950"):
+        slz4.Engine(0)
+    h = slz4.lib.LZ4_createStream()
+    src = (C.c_uint8 * 16)()
+    dst = (C.c_uint8 * 64)()
+    assert slz4.lib.LZ4_compress_fast_continue(h, src, dst, 16, 64, 1) == 0     # reference failure convention
+    slz4.lib.LZ4_freeStream(h)
+
+
+def _stream(oracle, n_blocks=7, bl=3000, has_size=True, kind="text"):
+    data = oracle.gen(kind, n_blocks, bl).tobytes()
+    return data, oracle.frame_compress(data, bl, 1, 8 if has_size else 4, True)
+
+
+@pytest.mark.parametrize("bufsize", [1, 512, 32 * 1024, 256 * 1024])      # test/Main.hs:217-224
+@pytest.mark.parametrize("has_size", [True, False])
+def test_resize_chunks_split_sizes(slz4, oracle, bufsize, has_size):
+    _, fr = _stream(oracle, has_size=has_size)
+    cfg = slz4.defaultBlockConfig if has_size else slz4.BlockConfig(slz4.BlockSize.BlockMax64KB)
+    chunks = [fr[i:i + bufsize] for i in range(0, len(fr), bufsize)]
+    got = slz4.resizeChunks(cfg, slz4.defaultFrameConfig, chunks)
+    assert got == framing.resize_chunks(chunks, has_size, False)
+    assert b"".join(got) == fr and len(got) == 7
+    for blk in got:
+        assert int.from_bytes(blk[:4], "little") + cfg.metaSize == len(blk)
+
+
+def test_resize_idempotence(slz4, oracle):                                    # test/Main.hs:189-201
+    rng = random.Random(5)
+    _, fr = _stream(oracle, n_blocks=9, bl=777)
+    cuts = sorted(rng.sample(range(1, len(fr)), 20))
+    chunks = [fr[a:b] for a, b in zip([0] + cuts, cuts + [len(fr)])]
+    chunks.insert(5, b"")        # an empty array inside a block is spliced away
+    once = slz4.resizeChunks(slz4.defaultBlockConfig, slz4.defaultFrameConfig, chunks)
+    acc = once
+    for _ in range(3):
+        acc = slz4.resizeChunks(slz4.defaultBlockConfig, slz4.defaultFrameConfig, acc)
+    assert acc == once == framing.resize_chunks(chunks)
+
+
+def test_resize_end_mark_and_errors(slz4, oracle):
+    _, fr = _stream(oracle, n_blocks=3, bl=500)
+    em = slz4.FrameConfig(True)
+    cfg = slz4.defaultBlockConfig
+    want = framing.resize_chunks([fr])
+    for bufsize in (1, 3, 64, 10 ** 6):                                       # test/Main.hs:109-139
+        s = fr + bytes(4) + b"trailing bytes are ignored"
+        chunks = [s[i:i + bufsize] for i in range(0, len(s), bufsize)]
+        assert slz4.resizeChunks(cfg, em, chunks) == want == framing.resize_chunks(chunks, True, True)
+    with pytest.raises(slz4.LZ4Error, match="No end mark found"):             # Internal/LZ4.hs:495
+        slz4.resizeChunks(cfg, em, [fr])
+    with pytest.raises(slz4.LZ4Error, match="Incomplete block"):              # Internal/LZ4.hs:505
+        slz4.resizeChunks(cfg, slz4.defaultFrameConfig, [fr[:-1]])
+    # a cut end mark never reaches RFooter (it needs >= 4 bytes to be recognised, :461-466), so the
+    # reference reports it as an incomplete block; ":517 Incomplete footer" is unreachable
+    with pytest.raises(slz4.LZ4Error, match="Incomplete block"):
+        slz4.resizeChunks(cfg, em, [fr, b"\0\0"])
+    with pytest.raises(framing.RefError, match="Incomplete block"):
+        framing.resize_chunks([fr, b"\0\0"], True, True)
+    assert slz4.resizeChunks(cfg, slz4.defaultFrameConfig, []) == []
+    # faithful quirk: an empty array at a block boundary starts accumulating and then hits Stop (:461-462,505)
+    with pytest.raises(slz4.LZ4Error, match="Incomplete block"):
+        slz4.resizeChunks(cfg, slz4.defaultFrameConfig, [fr, b""])
+    with pytest.raises(framing.RefError, match="Incomplete block"):
+        framing.resize_chunks([fr, b""])
+
+
+def test_simple_frame_parser(slz4):
+    hdr = bytes([0x04, 0x22, 0x4D, 0x18, 0x40, 0x40, 0x00])                  # test/Main.hs:145-151
+    for split in ([hdr + b"rest"], [hdr[:3], hdr[3:] + b"re", b"st"], [bytes([b]) for b in hdr + b"rest"]):
+        (cfg, fc), rest = slz4.simpleFrameParser(split)
+        assert cfg.blockSize == slz4.BlockSize.BlockMax64KB and fc.hasEndMark
+        assert b"".join(rest) == b"rest"
+    for bd, want in ((0x40, 1), (0x50, 2), (0x60, 3), (0x70, 4)):
+        (cfg, _), _ = slz4.simpleFrameParser([hdr[:5] + bytes([bd, 0])])
+        assert cfg.blockSize == want
+        assert framing.simple_frame_parser(hdr[:5] + bytes([bd, 0]))[0] == cfg.fixedUncomp
+    bad = {
+        bytes([0x05, 0x22, 0x4D, 0x18, 0x40, 0x40, 0]): "does not match",
+        hdr[:4] + bytes([0x80, 0x40, 0]): "Version is not 01",
+        hdr[:4] + bytes([0x60, 0x40, 0]): "Block independence is not yet supported",
+        hdr[:4] + bytes([0x50, 0x40, 0]): "Block checksum is not yet supported",
+        hdr[:4] + bytes([0x48, 0x40, 0]): "Content size is not yet supported",
+        hdr[:4] + bytes([0x44, 0x40, 0]): "Content checksum is not yet supported",
+        hdr[:4] + bytes([0x41, 0x40, 0]): "Dict is not yet supported",
+        hdr[:4] + bytes([0x40, 0x30, 0]): "Unknown block max size",
+    }
+    for data, msg in bad.items():
+        with pytest.raises(slz4.LZ4Error, match=msg):
+            slz4.simpleFrameParser([data])
+        with pytest.raises(framing.RefError, match=msg):
+            framing.simple_frame_parser(data)
+
+
+def test_index_host(slz4, oracle):
+    data, fr = _stream(oracle, n_blocks=5, bl=1234)
+    src = np.frombuffer(fr, dtype=np.uint8)
+    boff = np.zeros(8, dtype=np.uint64)
+    ulen = np.zeros(8, dtype=np.int32)
+    nb = C.c_int()
+    u8p, u64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    rc = slz4.lib.mi355lz4_index_host(src.ctypes.data_as(u8p), src.size, 8, 0, boff.ctypes.data_as(u64p),
+                                      ulen.ctypes.data_as(i32p), 8, C.byref(nb))
+    assert rc == 0 and nb.value == 5 and list(ulen[:5]) == [1234] * 5
+    want, pos = [], 0
+    for c, u, _ in framing.split_frames(fr):
+        want.append(pos)
+        pos += 8 + c
+    assert list(boff[:5]) == want
+    # truncated chain / too many blocks
+    assert slz4.lib.mi355lz4_index_host(src.ctypes.data_as(u8p), src.size - 1, 8, 0, boff.ctypes.data_as(u64p),
+                                        ulen.ctypes.data_as(i32p), 8, C.byref(nb)) == -6
+    assert slz4.lib.mi355lz4_index_host(src.ctypes.data_as(u8p), src.size, 8, 0, boff.ctypes.data_as(u64p),
+                                        ulen.ctypes.data_as(i32p), 3, C.byref(nb)) == -4
