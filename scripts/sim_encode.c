@@ -1,0 +1,69 @@
+// Development aid: CPU simulation of the wave-parallel match finder in
+// streamly-lz4_amd/csrc/encode_wave.hpp (sizes only), to tune ratio without a GPU.
+// Build: gcc -O2 -I oracle scripts/sim_encode.c oracle/lz4_oracle.c -o /tmp/sim_encode
+#include "lz4_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static uint32_t hash5(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return (uint32_t)(((v << 24) * 889523592379ULL) >> 52); }
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+static int VARIANT = 0;
+
+static int sim(const uint8_t *src, int n, int accel)
+{
+    static uint32_t table[4096];
+    memset(table, 0, sizeof(table));
+    long out = 0; int anchor = 0;
+    if (n == 0) return 1;
+    if (n >= 13) {
+        int mfl = n - 11, matchlimit = n - 5;
+        uint32_t miss0 = (uint32_t)accel << 6, missAcc = miss0;
+        long p = 0;
+        while (p < mfl) {
+            long step = missAcc >> 6;
+            int first = 64; long pos[64]; uint32_t cand[64], h[64]; int valid[64];
+            for (int l = 0; l < 64; l++) {
+                long off = (VARIANT & 1) ? (l < 3 ? l : 2 + (l - 2) * step) : l * step;   // variant 1: p, p+1, p+2, p+2+step...
+                pos[l] = p + off; valid[l] = pos[l] < mfl;
+                if (!valid[l]) continue;
+                h[l] = hash5(src + pos[l]); cand[l] = table[h[l]];
+                if (first == 64 && cand[l] < pos[l] && pos[l] - cand[l] <= 65535 && rd32(src + cand[l]) == rd32(src + pos[l])) first = l;
+            }
+            for (int l = 0; l < 64; l++) if (valid[l] && l <= first) table[h[l]] = (uint32_t)pos[l];
+            if (first == 64) { missAcc += 64; p = pos[63] + step; if (!(VARIANT&1)) p = p; continue; }
+            int mpos = (int)pos[first], cpos = (int)cand[first];
+            while (mpos > anchor && cpos > 0 && src[mpos - 1] == src[cpos - 1]) { mpos--; cpos--; }
+            int ml = 4; while (mpos + ml < matchlimit && src[mpos + ml] == src[cpos + ml]) ml++;
+            int lit = mpos - anchor, mc = ml - 4;
+            out += 1 + lit + 2 + (lit >= 15 ? (lit - 15) / 255 + 1 : 0) + (mc >= 15 ? (mc - 15) / 255 + 1 : 0);
+            anchor = mpos + ml; p = anchor; missAcc = miss0;
+            if (VARIANT & 2) { if (anchor - 2 >= 0 && anchor < mfl) table[hash5(src + anchor - 2)] = anchor - 2; }
+        }
+    }
+    int last = n - anchor;
+    out += 1 + last + (last >= 15 ? (last - 15) / 255 + 1 : 0);
+    return (int)out;
+}
+
+int main(int argc, char **argv)
+{
+    const char *kind = argc > 1 ? argv[1] : "lzsynth";
+    int bl = argc > 2 ? atoi(argv[2]) : 65536, nb = argc > 3 ? atoi(argv[3]) : 16;
+    uint8_t *buf = malloc(bl), *dst = malloc(bl + bl / 255 + 64);
+    int accels[] = {1, 2, 5, 20, 400};
+    for (int ai = 0; ai < 5; ai++) {
+        long ref = 0, s[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; b++) {
+            if (!strcmp(kind, "lzsynth")) orc_gen_lzsynth(buf, bl, b, 16, 2048);
+            else if (!strcmp(kind, "text")) orc_gen_text(buf, bl, b);
+            else orc_gen_random(buf, bl, b);
+            ref += orc_compress_block(buf, dst, bl, bl + bl / 255 + 16, accels[ai]);
+            for (VARIANT = 0; VARIANT < 4; VARIANT++) s[VARIANT] += sim(buf, bl, accels[ai]);
+        }
+        printf("%s accel %3d: ref %.4f | v0 %.4f v1 %.4f v2 %.4f v3 %.4f (ratio)\n", kind, accels[ai],
+               (double)nb * bl / ref, (double)nb * bl / s[0], (double)nb * bl / s[1], (double)nb * bl / s[2], (double)nb * bl / s[3]);
+    }
+    return 0;
+}

@@ -18,7 +18,8 @@
 //   * token / lengths / offset are emitted exactly as :1022-1046, :1065-1135,
 //     literals are copied by all lanes.
 // Acceleration keeps the reference meaning (:634, :957-967): the probe stride
-// is (accel*64 + misses) >> 6, with 64 misses charged per fruitless window.
+// is (accel*64 + misses) >> 6, with 64 misses charged per fruitless window; the
+// first three probes after a match are adjacent, as in the reference.
 // End-of-block rules (:214-221, :883-884): inputs < 13 bytes are all literals,
 // no match starts within the last 12 bytes, the last 5 bytes are literals.
 //
@@ -76,8 +77,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         int64_t p = 0;
 
         while (p < mfl) {
+            // probe positions p, p+1, p+2, then every `step`: like the reference, which probes
+            // ip, ip+1, ip+2 after each match before its stride takes over (:1159, :1200, :956-967)
             const int64_t step = (int64_t)(missAcc >> 6);
-            const int64_t myPos64 = p + (int64_t)lane * step;
+            const int64_t myPos64 = p + (lane < 3 ? (int64_t)lane : 2 + (int64_t)(lane - 2) * step);
             const bool valid = myPos64 < (int64_t)mfl;
             const int myPos = valid ? (int)myPos64 : 0;
             uint64_t v8 = 0;
@@ -96,7 +99,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (!m) {
                 if (missAcc < 0x7fffff00u) missAcc += LZ4_WAVE;
-                p += step * LZ4_WAVE;
+                p += 2 + 62 * step;
                 continue;
             }
             int mpos = __builtin_amdgcn_readlane(myPos, first);
@@ -146,6 +149,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             anchor = mpos + ml;
             p = anchor;
             missAcc = miss0;
+            // :1146 -- the reference registers ip-2 after every match
+            if (anchor < mfl && lane == 0) table[hash5(*(const u64_unaligned *)(src + anchor - 2))] = (TabT)(anchor - 2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 
