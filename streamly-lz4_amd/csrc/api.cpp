@@ -56,6 +56,7 @@ struct mi355lz4_ctx {
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
     DevBuf pinIn, pinOut;   // pinned host staging
+    unsigned long long *stats = nullptr;   // diagnostics: device counters of the lane-parallel decoder (off by default)
 };
 
 static int dev_reserve(DevBuf &b, size_t bytes)
@@ -156,6 +157,21 @@ extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
     return MI355LZ4_OK;
 }
 
+// Diagnostic hook (not part of the public header): enable/read the lane-parallel decoder's
+// phase counters.  enable != 0 switches the STATS kernel on (slower); out receives and resets
+// PAR_STATS_COUNT counters.
+extern "C" int mi355lz4_debug_stats(mi355lz4_ctx *c, int enable, unsigned long long *out)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stats && out) HIP_TRY(hipMemcpy(out, c->stats, PAR_STATS_COUNT * 8, hipMemcpyDeviceToHost));
+    if (enable && !c->stats) HIP_TRY(hipMalloc((void **)&c->stats, PAR_STATS_COUNT * 8));
+    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, PAR_STATS_COUNT * 8));
+    if (!enable && c->stats) { hipFree(c->stats); c->stats = nullptr; }
+    return MI355LZ4_OK;
+}
+
 extern "C" int mi355lz4_compress_bound(int n)
 {
     if ((unsigned)n > (unsigned)MI355LZ4_MAX_INPUT_SIZE) return 0;
@@ -232,7 +248,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
     if (c->decoder != 1)
-        launch_decode_par(a, c->stream);
+        launch_decode_par(a, c->stats, c->stream);
     else
         launch_decode_seq(a, c->stream);
     if (linked) launch_decode_fixup_linked(a, c->stream);

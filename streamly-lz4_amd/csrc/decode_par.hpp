@@ -1,0 +1,434 @@
+// decode_par.hpp -- lane-parallel LZ4 block decoder: one wavefront per block,
+// up to 64 sequences per iteration.
+//
+// Same contract and same results as decode_seq.hpp (reference
+// LZ4_decompress_generic, cbits/lz4.c:1737-2165): this file only changes HOW the
+// interior of a block is decoded.  A sequence-at-a-time decoder is bound by the
+// serial token chain (cbits/lz4.c:1801-1854: sequence i+1 starts where sequence i
+// ends) at ~30-50 issue slots and two dependent memory round trips per ~27-byte
+// sequence.  Here one iteration handles a BATCH of sequences:
+//
+//   1. window     1 KiB of the compressed stream is staged in LDS (16 B / lane;
+//                 the next window is prefetched into registers while this one is used).
+//   2. speculate  every lane parses 8 candidate token positions (512 candidates)
+//                 from registers: where would the next token be if one started here?
+//   3. chain      pointer jumping over that successor table: after round k lanes
+//                 0..2^k-1 hold the first 2^k real token positions, so 6 rounds put
+//                 sequence r on lane r -- the serial chain is resolved in log time.
+//   4. decode     lane r decodes sequence r (lengths, offset); a DPP wave scan of the
+//                 output lengths gives every sequence its output position.
+//   5. far        matches whose source was already flushed to global memory are
+//                 fetched in one batched pass (no dependence on this batch).
+//   6. literals   lane-per-sequence copy, LDS window -> LDS output ring.
+//   7. matches    dependency rounds: a match is ready when every sequence its
+//                 source overlaps is complete (64-bit ballot mask); ready lanes copy
+//                 8 bytes per step in lock step inside the LDS ring.
+//   8. flush      completed output leaves the ring with aligned 16-byte stores.
+//
+// Only "plain interior" sequences are handled here: single-byte length
+// extensions, offset != 0, source inside the block, far enough from both ends
+// that the reference would still be in its fast loop and could not fail.  On
+// anything else the block position is handed to decode_seq_run() for ONE
+// sequence (or for the rest of the block near its end), which is also what
+// produces the reference's exact error codes.
+#pragma once
+
+#include "decode_seq.hpp"
+
+namespace lz4dev {
+
+#define PAR_NODES 512       // speculative token candidates per window (8 per lane)
+#define PAR_WIN 1024        // bytes of compressed stream staged per window (16 per lane)
+#define PAR_RING 7168       // LDS output staging
+#define PAR_HIST 2048       // bytes of history kept in the ring across a slide
+#define PAR_BATCH_OUT 2560  // max output bytes of one batch
+
+struct __attribute__((aligned(16))) ParLds {
+    uint8_t win[PAR_WIN + 32];
+    uint16_t jump[PAR_NODES + 8];     // successor table; jump[PAR_NODES] == PAR_NODES (absorbing)
+    uint8_t ring[PAR_RING + 32];
+};
+
+typedef uint64_t par_u64u __attribute__((aligned(1)));
+typedef uint32_t par_u32u __attribute__((aligned(1)));
+typedef uint16_t par_u16u __attribute__((aligned(1)));
+
+__device__ __forceinline__ int par_bperm(int v, int srcLane)
+{
+    return __builtin_amdgcn_ds_bpermute(srcLane << 2, v);
+}
+
+// value of lane (l - d), for d in {1,2,4,8} and l, l-d in the same row of 16 lanes (else 0)
+template <int D>
+__device__ __forceinline__ int par_row_shr(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 | D, 0xf, 0xf, true);
+}
+
+// inclusive wave scan (sum) with DPP: 4 in-row steps + 2 row broadcasts
+__device__ __forceinline__ int par_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+
+// Diagnostic counters (STATS build only; never part of a timed run)
+enum { PS_BATCHES, PS_SEQS, PS_ROUNDS, PS_MATCH_ITERS, PS_LIT_ITERS, PS_HANDOVERS, PS_SLIDES, PS_FULL, PS_FAR,
+       PS_T_WINDOW, PS_T_SPEC, PS_T_CHAIN, PS_T_DECODE, PS_T_LIT, PS_T_NEED, PS_T_MATCH, PS_T_FLUSH, PS_T_SEQ, PS_COUNT };
+
+template <bool STATS>
+__device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *bufLo,
+                                const uint8_t *bufHi, ParLds &L, unsigned long long *stats)
+{
+    unsigned long long sc[PS_COUNT];
+    unsigned long long tmark = 0;
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < PS_COUNT; i++) sc[i] = 0;
+        tmark = __builtin_amdgcn_s_memtime();
+    }
+    auto lap = [&](int which) {
+        if (STATS) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            sc[which] += now - tmark;
+            tmark = now;
+        }
+    };
+    auto publish = [&]() {
+        if (STATS && lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], sc[i]);
+        }
+    };
+    if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+
+    const int lane = lane_id();
+    const int iend = srcLen;
+    const uint32_t A = (uint32_t)((uintptr_t)dst & 15);   // ring index of output position p is p - ringBase + A
+    int ip = 0, op = 0;
+    int ringBase = 0;       // multiple of 16
+    int flushed = 0;        // output positions < flushed are in global memory
+    SeqState st;
+
+    if (lane == 0) L.jump[PAR_NODES] = PAR_NODES;
+
+    // 16 bytes of the compressed stream for this lane's slot of the window that starts at `base`
+    auto fetch_window = [&](uintptr_t base) -> uint4 {
+        const uint8_t *q = (const uint8_t *)(base + 16u * (uint32_t)lane);
+        if (q >= bufLo && q + 16 <= bufHi) return *(const uint4 *)q;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; k++)
+            if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)q[k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+
+    // ring -> global for positions [flushed, upto); 16-byte aligned stores in the body.
+    auto flush = [&](int upto, bool final) {
+        wave_fence();
+        int f = flushed;
+        const int mis = (int)((A + (uint32_t)f) & 15u);
+        if (mis) {
+            const int head = 16 - mis;
+            if (upto - f >= head) {
+                if (lane < head) dst[f + lane] = L.ring[f - ringBase + (int)A + lane];
+                f += head;
+            } else if (!final) {
+                return;
+            }
+        }
+        if (((A + (uint32_t)f) & 15u) == 0) {
+            const int n16 = (upto - f) >> 4;
+            for (int c = lane; c < n16; c += LZ4_WAVE) {
+                const uint4 v = *(const uint4 *)&L.ring[f - ringBase + (int)A + 16 * c];
+                *(uint4 *)(dst + f + 16 * c) = v;
+            }
+            f += n16 << 4;
+        }
+        if (final) {
+            for (int x = f + lane; x < upto; x += LZ4_WAVE) dst[x] = L.ring[x - ringBase + (int)A];
+            f = upto;
+        }
+        flushed = f;
+        wave_fence();
+    };
+
+    uintptr_t wbase = (uintptr_t)src & ~(uintptr_t)15;     // window base whose data is in `wnext`
+    uint4 wnext = fetch_window(wbase);
+
+    for (;;) {
+        if (iend - ip < 64 || cap - op < 128) break;
+        lap(PS_T_FLUSH);
+
+        // ---------------- 1. window ----------------
+        const uint8_t *gp = src + ip;
+        const uintptr_t abase = (uintptr_t)gp & ~(uintptr_t)15;
+        const int wofs = (int)((uintptr_t)gp - abase);
+        const int ipW0 = ip - wofs;                    // block-relative position of window byte 0
+        const int iendW = iend - ipW0;                 // block end in window coordinates
+        if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); }   // prefetch missed (handover path)
+        *(uint4 *)&L.win[16 * lane] = wnext;
+        wave_fence();
+        lap(PS_T_WINDOW);
+
+        // ---------------- 2. speculative parse (registers only) ----------------
+        uint32_t J[8];
+        {
+            const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
+            const uint32_t hi = (uint32_t)L.win[8 * lane + 8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t t = (uint32_t)(lo >> (8 * j)) & 0xffu;
+                const uint32_t b1 = (j < 7) ? ((uint32_t)(lo >> (8 * (j + 1))) & 0xffu) : hi;
+                const bool is15 = (t >> 4) == 15u;
+                const uint32_t litv = is15 ? 15u + b1 : (t >> 4);
+                const uint32_t nxt = 8u * (uint32_t)lane + (uint32_t)j + 1u + (is15 ? 1u : 0u) + litv + 2u +
+                                     (((t & 15u) == 15u) ? 1u : 0u);
+                // (a 255 match-length byte is caught when the real token is decoded, step 4)
+                const bool good = !(is15 && b1 == 255u) && (int)nxt + 32 <= iendW && nxt <= PAR_WIN;
+                J[j] = (good && nxt < PAR_NODES) ? nxt : PAR_NODES;
+            }
+            *(uint4 *)&L.jump[8 * lane] =
+                make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
+        }
+        wave_fence();
+        lap(PS_T_SPEC);
+
+        // ---------------- 3. chain: sequence r -> lane r ----------------
+        int c = (lane == 0) ? wofs : PAR_NODES;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int d = 1 << k;
+            const int cj = (int)L.jump[c];
+            if (k < 5) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) J[j] = (uint32_t)L.jump[J[j]];
+            }
+            int sh;
+            if (k == 0) sh = par_row_shr<1>(cj);
+            else if (k == 1) sh = par_row_shr<2>(cj);
+            else if (k == 2) sh = par_row_shr<4>(cj);
+            else if (k == 3) sh = par_row_shr<8>(cj);
+            else sh = par_bperm(cj, (lane - d) & 63);
+            if (lane >= d && lane < 2 * d) c = sh;
+            if (k < 5) {
+                wave_fence();
+                *(uint4 *)&L.jump[8 * lane] =
+                    make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
+                wave_fence();
+            }
+        }
+        lap(PS_T_CHAIN);
+
+        // ---------------- 4. decode own sequence, place it ----------------
+        const bool has = c < PAR_NODES;
+        const uint32_t cc = has ? (uint32_t)c : 0u;
+        const uint32_t tb = (uint32_t)(*(const par_u16u *)&L.win[cc]);      // token, next byte
+        const uint32_t t = tb & 0xffu, b1 = tb >> 8;
+        const bool is15 = (t >> 4) == 15u;
+        const uint32_t lit = is15 ? 15u + b1 : (t >> 4);
+        const uint32_t litStart = cc + 1u + (is15 ? 1u : 0u);
+        const uint32_t offPos = litStart + lit;                             // <= 511 + 272: inside the window
+        const uint32_t ob = *(const par_u32u *)&L.win[offPos];              // offset (2 bytes), match-length byte
+        const uint32_t off16 = ob & 0xffffu, b2 = (ob >> 16) & 0xffu;
+        const bool mlx = (t & 15u) == 15u;
+        const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
+        const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u);
+        bool ok = has && !(is15 && b1 == 255u) && !(mlx && b2 == 255u) && (int)nxt + 32 <= iendW && nxt <= PAR_WIN &&
+                  off16 != 0;
+        const int len = ok ? (int)(lit + ml) : 0;
+        const int incl = par_scan_incl(len);
+        const int outEnd = op + incl;
+        const int outStart = outEnd - len;
+        const int dpos = outStart + (int)lit;            // match destination
+        const int spos = dpos - (int)off16;              // match source
+        ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap && spos >= 0 &&
+             (spos >= ringBase || spos + (int)ml <= flushed);
+        const uint64_t okm = __ballot(ok);
+        const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
+        lap(PS_T_DECODE);
+        if (STATS) { sc[PS_BATCHES]++; sc[PS_SEQS] += (unsigned)nseq; if (nseq == LZ4_WAVE) sc[PS_FULL]++; }
+
+        if (nseq == 0) {
+            // not a plain interior sequence: the sequential decoder takes exactly one sequence
+            if (STATS) sc[PS_HANDOVERS]++;
+            flush(op, true);
+            st.ip = ip; st.op = op; st.fast = true;
+            const int r = decode_seq_run(st, 1, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+            if (r != SEQ_CONTINUE) { lap(PS_T_SEQ); publish(); return r; }
+            ip = st.ip; op = st.op;
+            if (!st.fast || iend - ip < 64 || cap - op < 128) {
+                const int r2 = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+                lap(PS_T_SEQ); publish();
+                return r2;
+            }
+            // reload the ring's history from global memory
+            wave_fence();
+            ringBase = (op > PAR_HIST) ? ((op - PAR_HIST) & ~15) : 0;
+            flushed = op;
+            for (int x = ringBase + lane; x < op; x += LZ4_WAVE) L.ring[x - ringBase + (int)A] = dst[x];
+            wave_fence();
+            lap(PS_T_SEQ);
+            continue;
+        }
+
+        const bool act = lane < nseq;
+        const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
+        const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
+        // prefetch the next window while this batch is copied
+        {
+            const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
+            wbase = nb;
+            wnext = fetch_window(nb);
+        }
+
+        const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
+        const bool nearSrc = spos >= ringBase;
+        const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
+        const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
+
+        // ---------------- 5. far matches: source already in global memory ----------------
+        uint64_t farm = __ballot(act && !nearSrc);
+        if (farm) {
+            if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
+            const uint8_t *gsrc = dst + spos;
+            const bool mine = act && !nearSrc;
+            // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
+            // past the match is written.  Far sources never overlap their destination.
+            const uint32_t step = (ml >= 8) ? 8u : 4u;
+            const uint32_t last = ml - step;
+            for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
+                if (mine && base < ml) {
+                    if (step == 8) {
+                        uint64_t v[4];
+                        uint32_t o[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)(gsrc + o[k]); }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
+                    } else {
+                        const uint32_t v0 = *(const par_u32u *)(gsrc);
+                        const uint32_t v1 = *(const par_u32u *)(gsrc + last);
+                        *(par_u32u *)&L.ring[mdA] = v0;
+                        *(par_u32u *)&L.ring[mdA + last] = v1;
+                    }
+                }
+            }
+        }
+
+        // ---------------- 6. literals: window -> ring ----------------
+        {
+            const uint32_t sA = litStart;
+            const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
+            const uint32_t n = act ? lit : 0u;
+            if (n >= 8) {
+                const uint32_t last = n - 8;
+                for (uint32_t o = 0;; o += 8) {
+                    const uint32_t oo = min(o, last);
+                    *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
+                    if (o >= last) break;
+                }
+            } else if (n >= 4) {
+                const uint32_t v0 = *(const par_u32u *)&L.win[sA], v1 = *(const par_u32u *)&L.win[sA + n - 4];
+                *(par_u32u *)&L.ring[dA] = v0;
+                *(par_u32u *)&L.ring[dA + n - 4] = v1;
+            } else if (n > 0) {
+                const uint32_t v = *(const par_u32u *)&L.win[sA];
+                L.ring[dA] = (uint8_t)v;
+                if (n > 1) L.ring[dA + 1] = (uint8_t)(v >> 8);
+                if (n > 2) L.ring[dA + 2] = (uint8_t)(v >> 16);
+            }
+        }
+        wave_fence();
+        lap(PS_T_LIT);
+
+        // ---------------- 7. near matches: dependency rounds ----------------
+        uint64_t need = 0;
+        {
+            // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
+            const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
+            const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
+            int jlo = 0, jhi = 0;
+#pragma unroll
+            for (int stp = 32; stp >= 1; stp >>= 1) {
+                const int c1 = jlo + stp, c2 = jhi + stp;
+                const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, c2 & 63);
+                if (c1 < nseq && v1 <= xlo) jlo = c1;
+                if (c2 < nseq && v2 <= xhi) jhi = c2;
+            }
+            if (act && nearSrc && srcHi > op && srcHi > spos) {
+                const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
+                need = upto & ~((1ull << jlo) - 1ull);
+                need &= ~(1ull << lane);
+                need &= ~farm;                                      // far matches are already in place
+            }
+        }
+        lap(PS_T_NEED);
+        uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
+        const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
+        while (~done) {
+            const bool mine = !((done >> lane) & 1ull) && ((need & ~done) == 0ull);
+            if (STATS) sc[PS_ROUNDS]++;
+            // wide lanes: 8- or 4-byte steps, last chunk re-anchored at the end (idempotent rewrite)
+            {
+                const uint32_t step = w8 ? 8u : 4u;
+                const uint32_t last = ml - step;
+                const bool wide = mine && (w8 || w4);
+                for (uint32_t o = 0; __ballot(wide && o < ml); o += step) {
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    if (wide && o < ml) {
+                        const uint32_t oo = min(o, last);
+                        if (w8) *(par_u64u *)&L.ring[mdA + oo] = *(const par_u64u *)&L.ring[msA + oo];
+                        else *(par_u32u *)&L.ring[mdA + oo] = *(const par_u32u *)&L.ring[msA + oo];
+                    }
+                    wave_fence();
+                }
+            }
+            // offsets 1..3: byte steps
+            if (__ballot(mine && !w8 && !w4)) {
+                const bool slow = mine && !w8 && !w4;
+                for (uint32_t o = 0; __ballot(slow && o < ml); o++) {
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    if (slow && o < ml) L.ring[mdA + o] = L.ring[msA + o];
+                    wave_fence();
+                }
+            }
+            done |= __ballot(mine);
+        }
+        wave_fence();
+        lap(PS_T_MATCH);
+
+        // ---------------- advance, 8. flush, slide ----------------
+        op = opNext;
+        ip = ipNext;
+        flush(op, false);
+        if (op - ringBase + (int)A + PAR_BATCH_OUT + 32 > PAR_RING) {
+            if (STATS) sc[PS_SLIDES]++;
+            const int newBase = (op - PAR_HIST) & ~15;
+            const int delta = newBase - ringBase;
+            const int n16 = (op - newBase + (int)A + 15) >> 4;
+            for (int k = lane; k < n16; k += LZ4_WAVE) {
+                const uint4 v = *(const uint4 *)&L.ring[delta + 16 * k];
+                wave_fence();
+                *(uint4 *)&L.ring[16 * k] = v;
+            }
+            ringBase = newBase;
+            wave_fence();
+        }
+    }
+
+    // tail of the block (and every end-of-block rule) belongs to the sequential decoder
+    flush(op, true);
+    st.ip = ip; st.op = op; st.fast = true;
+    lap(PS_T_FLUSH);
+    const int rfin = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+    lap(PS_T_SEQ);
+    publish();
+    return rfin;
+}
+
+} // namespace lz4dev

@@ -30,9 +30,11 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dst, int op, int match,
     const uint32_t lane = (uint32_t)lane_id();
     wave_fence();
     if (offset == 0) {
+#pragma unroll 1
         for (uint32_t j = lane; j < ml; j += LZ4_WAVE) dst[op + j] = 0;
     } else if (offset >= LZ4_WAVE) {
         // chunk c may read what chunk c-1 wrote: stores and loads of one wave stay in order
+#pragma unroll 1
         for (uint32_t c = 0; c < ml; c += LZ4_WAVE) {
             uint32_t j = c + lane;
             if (j < ml) {
@@ -43,6 +45,7 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dst, int op, int match,
         }
     } else {
         // short period: every source byte lies in [match, op), complete before this sequence
+#pragma unroll 1
         for (uint32_t j = lane; j < ml; j += LZ4_WAVE) {
             int s = match + (int)(j % offset);
             dst[op + j] = (s < 0) ? dict[(int)dictLen + s] : dst[s];
@@ -51,38 +54,44 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dst, int op, int match,
     wave_fence();
 }
 
-// Decode one block.  All arguments are wave-uniform.  [bufLo, bufHi) bounds the
-// readable framed buffer (reads outside return 0 instead of faulting).
-__device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
-                                const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo,
-                                const uint8_t *bufHi)
+// Resumable decoder state (all wave-uniform).
+struct SeqState {
+    int ip;      // next token, relative to the block's first compressed byte
+    int op;      // bytes of output produced so far
+    bool fast;   // which of the reference's two loops would be running (:1791)
+};
+#define SEQ_CONTINUE ((int)0x80000000)   // decode_seq_run: sequence budget used up, block not finished
+
+// Decode up to maxSeq sequences (maxSeq <= 0: until the block ends) starting at st.
+// Returns SEQ_CONTINUE, or the block's final result: decoded size >= 0 or the
+// reference's negative code.  [bufLo, bufHi) bounds the readable framed buffer
+// (reads outside return 0 instead of faulting).
+__device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                              const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi)
 {
     const int iend = srcLen, oend = cap;
     const bool useDict = (dict != nullptr) && dictLen > 0;
     const bool checkOffset = dictLen < 65536u;                 // cbits/lz4.c:1764
-    int ip = 0, op = 0;
+    int ip = st.ip, op = st.op;
     uint32_t token = 0, ll = 0, ml = 0, offset = 0, s = 0;
     int match = 0;
-    bool fast;
-
-    if (cap == 0) {                                              // :1781-1785
-        InWindow w0; w0.lo = bufLo; w0.hi = bufHi; w0.load(src);
-        return (srcLen == 1 && w0.byte_at(src) == 0) ? 0 : -1;
-    }
-    if (srcLen == 0) return -1;                                  // :1787
+    bool fast = st.fast;
+    int budget = maxSeq;
 
     InWindow win;
     win.lo = bufLo; win.hi = bufHi;
-    win.load(src);
+    win.load(src + ip);
     auto rd = [&](int pos) -> uint32_t {
         const uint8_t *p = src + pos;
         if (!win.covers(p, 1)) win.load(p);
         return win.byte_at(p);
     };
 
-    fast = (oend - op) >= 64;                                    // :1791
-
     for (;;) {
+        if (maxSeq > 0) {
+            if (budget == 0) { st.ip = ip; st.op = op; st.fast = fast; return SEQ_CONTINUE; }
+            budget--;
+        }
         token = rd(ip); ip++;
         ll = token >> 4;
 
@@ -170,6 +179,22 @@ __device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, in
 
 error:
     return -ip - 1;                                                           // :2163
+}
+
+// Decode one whole block.  All arguments are wave-uniform.
+__device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                                const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo,
+                                const uint8_t *bufHi)
+{
+    if (cap == 0) {                                              // :1781-1785
+        InWindow w0; w0.lo = bufLo; w0.hi = bufHi; w0.load(src);
+        return (srcLen == 1 && w0.byte_at(src) == 0) ? 0 : -1;
+    }
+    if (srcLen == 0) return -1;                                  // :1787
+    SeqState st;
+    st.ip = 0; st.op = 0;
+    st.fast = cap >= 64;                                         // :1791
+    return decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
 }
 
 } // namespace lz4dev

@@ -10,6 +10,7 @@
 #include "kernels.h"
 
 #include "decode_seq.hpp"
+#include "decode_par.hpp"
 #include "encode_wave.hpp"
 
 using namespace lz4dev;
@@ -42,7 +43,7 @@ __device__ __forceinline__ int read_block_header(const DecodeArgs &a, int blk, c
 }
 
 // One wavefront per block, 4 blocks per 256-thread workgroup.
-__global__ __launch_bounds__(256) void k_decode_seq(DecodeArgs a)
+__global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
 {
     const int blk = uni((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
     if (blk >= a.nBlocks) return;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void k_decode_seq(DecodeArgs a)
 // its linked result; only blocks whose standalone decode failed are re-decoded
 // here, in stream order, with the dictionary in force.  The chain is serial, so
 // one wavefront walks it.  
-__global__ __launch_bounds__(64) void k_decode_fixup_linked(DecodeArgs a)
+__global__ __launch_bounds__(64, 6) void k_decode_fixup_linked(DecodeArgs a)
 {
     const uint8_t *dict = a.dict0;
     uint32_t dictLen = a.dict0 ? a.dict0Len : 0;
@@ -305,6 +306,26 @@ void launch_generate(int kind, uint8_t *dst, int blockLen, int nBlocks, uint64_t
                            blockLen, nBlocks, firstBlock, blockStep, litMax, offMax);
 }
 
-// Lane-parallel decoder entry (decode_par.hpp); until it lands every block takes the
-// sequence-at-a-time kernel.
-void launch_decode_par(const DecodeArgs &a, hipStream_t s) { launch_decode_seq(a, s); }
+// Lane-parallel decoder (decode_par.hpp): one wavefront (= one workgroup) per block.
+template <bool STATS>
+__global__ __launch_bounds__(64, 4) void k_decode_par(DecodeArgs a, unsigned long long *stats)
+{
+    __shared__ ParLds lds;
+    const int blk = (int)blockIdx.x;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = read_block_header(a, blk, data, compLen, cap);
+    if (r == 0)
+        r = decode_block_par<STATS>(data, compLen, a.out + a.outOff[blk], cap, a.framed, a.framed + a.framedLen, lds,
+                                    stats);
+    if (lane_id() == 0) a.result[blk] = r;
+}
+
+void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    if (stats)
+        hipLaunchKernelGGL(k_decode_par<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+    else
+        hipLaunchKernelGGL(k_decode_par<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+}

@@ -87,6 +87,7 @@ struct InWindow {
 // Wave-parallel byte copy, non-overlapping (literals: compressed stream -> output).
 __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
 {
+#pragma unroll 2
     for (uint32_t i = (uint32_t)lane_id(); i < n; i += LZ4_WAVE) dst[i] = src[i];
 }
 

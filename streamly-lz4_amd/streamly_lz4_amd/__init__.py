@@ -35,7 +35,24 @@ class LZ4Error(RuntimeError):
     """Raised where the reference calls `error` / `Parser.die`, with the same message."""
 
 
+def _preload_torch_hip():
+    """PyTorch wheels bundle their own HIP/HSA runtime (same SONAME as /opt/rocm's).  Two HSA
+    runtimes in one process do not coexist, so when torch is installed make its copy the one that
+    is loaded, whichever of torch / this package is imported first."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=os.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def _load():
+    _preload_torch_hip()
     if not os.path.exists(lib_path):
         raise ImportError(
             "streamly_lz4_amd: %s is missing -- build it with `make lib` (hipcc, gfx950). "
