@@ -39,13 +39,23 @@ namespace lz4dev {
 
 #define PAR_NODES 512       // speculative token candidates per window (8 per lane)
 #define PAR_WIN 1024        // bytes of compressed stream staged per window (16 per lane)
+#ifndef PAR_RING
 #define PAR_RING 7168       // LDS output staging
+#endif
+#ifndef PAR_HIST
 #define PAR_HIST 2048       // bytes of history kept in the ring across a slide
+#endif
+#ifndef PAR_BATCH_OUT
 #define PAR_BATCH_OUT 2560  // max output bytes of one batch
+#endif
+#ifndef PAR_WAVES
+#define PAR_WAVES 4         // occupancy target (waves per SIMD) the register allocator is held to
+#endif
 
+// The successor table of step 3 (PAR_NODES+8 uint16) lives in the part of the ring that this
+// batch's output will later overwrite: it is dead before the first output byte is written.
 struct __attribute__((aligned(16))) ParLds {
     uint8_t win[PAR_WIN + 32];
-    uint16_t jump[PAR_NODES + 8];     // successor table; jump[PAR_NODES] == PAR_NODES (absorbing)
     uint8_t ring[PAR_RING + 32];
 };
 
@@ -115,8 +125,6 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     int flushed = 0;        // output positions < flushed are in global memory
     SeqState st;
 
-    if (lane == 0) L.jump[PAR_NODES] = PAR_NODES;
-
     // 16 bytes of the compressed stream for this lane's slot of the window that starts at `base`
     auto fetch_window = [&](uintptr_t base) -> uint4 {
         const uint8_t *q = (const uint8_t *)(base + 16u * (uint32_t)lane);
@@ -176,6 +184,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         lap(PS_T_WINDOW);
 
         // ---------------- 2. speculative parse (registers only) ----------------
+        uint16_t *jump = (uint16_t *)&L.ring[((uint32_t)(op - ringBase) + A + 15u) & ~15u];
+        if (lane == 0) jump[PAR_NODES] = PAR_NODES;       // absorbing state
         uint32_t J[8];
         {
             const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
@@ -192,7 +202,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const bool good = !(is15 && b1 == 255u) && (int)nxt + 32 <= iendW && nxt <= PAR_WIN;
                 J[j] = (good && nxt < PAR_NODES) ? nxt : PAR_NODES;
             }
-            *(uint4 *)&L.jump[8 * lane] =
+            *(uint4 *)&jump[8 * lane] =
                 make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
         }
         wave_fence();
@@ -203,10 +213,10 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int d = 1 << k;
-            const int cj = (int)L.jump[c];
+            const int cj = (int)jump[c];
             if (k < 5) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) J[j] = (uint32_t)L.jump[J[j]];
+                for (int j = 0; j < 8; j++) J[j] = (uint32_t)jump[J[j]];
             }
             int sh;
             if (k == 0) sh = par_row_shr<1>(cj);
@@ -217,7 +227,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             if (lane >= d && lane < 2 * d) c = sh;
             if (k < 5) {
                 wave_fence();
-                *(uint4 *)&L.jump[8 * lane] =
+                *(uint4 *)&jump[8 * lane] =
                     make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
                 wave_fence();
             }
@@ -290,6 +300,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         const bool nearSrc = spos >= ringBase;
         const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
         const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
+        const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups are safe
 
         // ---------------- 5. far matches: source already in global memory ----------------
         uint64_t farm = __ballot(act && !nearSrc);
@@ -373,11 +384,26 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         while (~done) {
             const bool mine = !((done >> lane) & 1ull) && ((need & ~done) == 0ull);
             if (STATS) sc[PS_ROUNDS]++;
-            // wide lanes: 8- or 4-byte steps, last chunk re-anchored at the end (idempotent rewrite)
-            {
+            // lanes whose 32-byte groups never read their own writes: 4 x 8 bytes per step
+            for (uint32_t base = 0; __ballot(mine && grp && base < ml); base += 32) {
+                if (STATS) sc[PS_MATCH_ITERS]++;
+                if (mine && grp && base < ml) {
+                    const uint32_t last = ml - 8;
+                    uint64_t v[4];
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)&L.ring[msA + o[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
+                }
+                wave_fence();
+            }
+            // short-offset lanes: 8- or 4-byte steps one after the other (a step may read the previous
+            // step's bytes); last chunk re-anchored at the end (idempotent rewrite)
+            if (__ballot(mine && !grp && (w8 || w4))) {
                 const uint32_t step = w8 ? 8u : 4u;
                 const uint32_t last = ml - step;
-                const bool wide = mine && (w8 || w4);
+                const bool wide = mine && !grp && (w8 || w4);
                 for (uint32_t o = 0; __ballot(wide && o < ml); o += step) {
                     if (STATS) sc[PS_MATCH_ITERS]++;
                     if (wide && o < ml) {

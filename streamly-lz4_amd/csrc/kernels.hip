@@ -308,7 +308,7 @@ void launch_generate(int kind, uint8_t *dst, int blockLen, int nBlocks, uint64_t
 
 // Lane-parallel decoder (decode_par.hpp): one wavefront (= one workgroup) per block.
 template <bool STATS>
-__global__ __launch_bounds__(64, 4) void k_decode_par(DecodeArgs a, unsigned long long *stats)
+__global__ __launch_bounds__(64, PAR_WAVES) void k_decode_par(DecodeArgs a, unsigned long long *stats)
 {
     __shared__ ParLds lds;
     const int blk = (int)blockIdx.x;

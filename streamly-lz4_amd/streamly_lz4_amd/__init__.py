@@ -24,7 +24,8 @@ __all__ = [
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmi355lz4.so")
+# MI355LZ4_LIB lets a developer A/B another build of the same library (scripts/ab_variants.sh)
+lib_path = os.environ.get("MI355LZ4_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmi355lz4.so")
 
 _u8p = C.POINTER(C.c_uint8)
 _u64p = C.POINTER(C.c_uint64)
