@@ -215,6 +215,7 @@ extern "C" int mi355lz4_compress_batch_device(mi355lz4_ctx *c, const uint8_t *sr
     a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.blockStride = blockStride;
     a.uniformLen = maxBlockLen; a.nBlocks = nBlocks; a.accel = accel; a.headerKind = headerKind;
     a.slots = slots; a.slotStride = slotStride; a.framedLen = framedLen;
+    a.stats = c->stats;
     launch_encode(a, maxBlockLen > 65536, c->stream);
     return check_launch("encode launch");
 }

@@ -52,12 +52,14 @@ namespace lz4dev {
 #define PAR_WAVES 4         // occupancy target (waves per SIMD) the register allocator is held to
 #endif
 
-// The successor table of step 3 (PAR_NODES+8 uint16) lives in the part of the ring that this
-// batch's output will later overwrite: it is dead before the first output byte is written.
+// jump[] is the successor table of step 3.  Entries are BYTE offsets into jump[] itself (2 x node
+// index), so a gather is one ds_read_u16 with no address arithmetic; 2*PAR_NODES is the absorbing state.
 struct __attribute__((aligned(16))) ParLds {
     uint8_t win[PAR_WIN + 32];
+    uint16_t jump[PAR_NODES + 8];
     uint8_t ring[PAR_RING + 32];
 };
+#define PAR_END (2 * PAR_NODES)
 
 typedef uint64_t par_u64u __attribute__((aligned(1)));
 typedef uint32_t par_u32u __attribute__((aligned(1)));
@@ -167,294 +169,282 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
     uintptr_t wbase = (uintptr_t)src & ~(uintptr_t)15;     // window base whose data is in `wnext`
     uint4 wnext = fetch_window(wbase);
+    const uint8_t *jumpB = (const uint8_t *)L.jump;
+    if (lane == 0) L.jump[PAR_NODES] = PAR_END;            // absorbing state
 
     for (;;) {
-        if (iend - ip < 64 || cap - op < 128) break;
-        lap(PS_T_FLUSH);
+        // ================= hot loop: batches of plain interior sequences =================
+        while (iend - ip >= 64 && cap - op >= 128) {
+            lap(PS_T_FLUSH);
 
-        // ---------------- 1. window ----------------
-        const uint8_t *gp = src + ip;
-        const uintptr_t abase = (uintptr_t)gp & ~(uintptr_t)15;
-        const int wofs = (int)((uintptr_t)gp - abase);
-        const int ipW0 = ip - wofs;                    // block-relative position of window byte 0
-        const int iendW = iend - ipW0;                 // block end in window coordinates
-        if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); }   // prefetch missed (handover path)
-        *(uint4 *)&L.win[16 * lane] = wnext;
-        wave_fence();
-        lap(PS_T_WINDOW);
+            // ---------------- 1. window ----------------
+            const uint8_t *gp = src + ip;
+            const uintptr_t abase = (uintptr_t)gp & ~(uintptr_t)15;
+            const int wofs = (int)((uintptr_t)gp - abase);
+            const int ipW0 = ip - wofs;                    // block-relative position of window byte 0
+            const int iendW = iend - ipW0;                 // block end in window coordinates
+            const int inLim = min(iendW - 32, PAR_WIN);    // a plain sequence must end at or before this
+            if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); }   // no prefetch after a handover
+            *(uint4 *)&L.win[16 * lane] = wnext;
+            wave_fence();
+            lap(PS_T_WINDOW);
 
-        // ---------------- 2. speculative parse (registers only) ----------------
-        uint16_t *jump = (uint16_t *)&L.ring[((uint32_t)(op - ringBase) + A + 15u) & ~15u];
-        if (lane == 0) jump[PAR_NODES] = PAR_NODES;       // absorbing state
-        uint32_t J[8];
-        {
-            const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
-            const uint32_t hi = (uint32_t)L.win[8 * lane + 8];
+            // ---------------- 2. speculative parse (registers only) ----------------
+            uint32_t J[8];
+            {
+                const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
+                const uint32_t hi = (uint32_t)L.win[8 * lane + 8];
+                const uint32_t nodeLim = (uint32_t)min(inLim, PAR_NODES - 1);
+                const uint32_t base3 = 8u * (uint32_t)lane + 3u;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t t = (uint32_t)(lo >> (8 * j)) & 0xffu;
-                const uint32_t b1 = (j < 7) ? ((uint32_t)(lo >> (8 * (j + 1))) & 0xffu) : hi;
-                const bool is15 = (t >> 4) == 15u;
-                const uint32_t litv = is15 ? 15u + b1 : (t >> 4);
-                const uint32_t nxt = 8u * (uint32_t)lane + (uint32_t)j + 1u + (is15 ? 1u : 0u) + litv + 2u +
-                                     (((t & 15u) == 15u) ? 1u : 0u);
-                // (a 255 match-length byte is caught when the real token is decoded, step 4)
-                const bool good = !(is15 && b1 == 255u) && (int)nxt + 32 <= iendW && nxt <= PAR_WIN;
-                J[j] = (good && nxt < PAR_NODES) ? nxt : PAR_NODES;
-            }
-            *(uint4 *)&jump[8 * lane] =
-                make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
-        }
-        wave_fence();
-        lap(PS_T_SPEC);
-
-        // ---------------- 3. chain: sequence r -> lane r ----------------
-        int c = (lane == 0) ? wofs : PAR_NODES;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int d = 1 << k;
-            const int cj = (int)jump[c];
-            if (k < 5) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) J[j] = (uint32_t)jump[J[j]];
-            }
-            int sh;
-            if (k == 0) sh = par_row_shr<1>(cj);
-            else if (k == 1) sh = par_row_shr<2>(cj);
-            else if (k == 2) sh = par_row_shr<4>(cj);
-            else if (k == 3) sh = par_row_shr<8>(cj);
-            else sh = par_bperm(cj, (lane - d) & 63);
-            if (lane >= d && lane < 2 * d) c = sh;
-            if (k < 5) {
-                wave_fence();
-                *(uint4 *)&jump[8 * lane] =
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t t = (uint32_t)(lo >> (8 * j)) & 0xffu;
+                    const uint32_t b1 = (j < 7) ? ((uint32_t)(lo >> (8 * (j + 1))) & 0xffu) : hi;
+                    const uint32_t lit0 = t >> 4;
+                    // token + literals + 2 offset bytes (+1 literal-length byte, +1 match-length byte);
+                    // 255-valued length bytes are caught when the real token is decoded (step 4)
+                    uint32_t nxt = base3 + (uint32_t)j + ((lit0 == 15u) ? 16u + b1 : lit0);
+                    nxt += ((t & 15u) == 15u) ? 1u : 0u;
+                    J[j] = ((int)nxt <= (int)nodeLim) ? 2u * nxt : (uint32_t)PAR_END;
+                }
+                *(uint4 *)&L.jump[8 * lane] =
                     make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
-                wave_fence();
             }
-        }
-        lap(PS_T_CHAIN);
+            wave_fence();
+            lap(PS_T_SPEC);
 
-        // ---------------- 4. decode own sequence, place it ----------------
-        const bool has = c < PAR_NODES;
-        const uint32_t cc = has ? (uint32_t)c : 0u;
-        const uint32_t tb = (uint32_t)(*(const par_u16u *)&L.win[cc]);      // token, next byte
-        const uint32_t t = tb & 0xffu, b1 = tb >> 8;
-        const bool is15 = (t >> 4) == 15u;
-        const uint32_t lit = is15 ? 15u + b1 : (t >> 4);
-        const uint32_t litStart = cc + 1u + (is15 ? 1u : 0u);
-        const uint32_t offPos = litStart + lit;                             // <= 511 + 272: inside the window
-        const uint32_t ob = *(const par_u32u *)&L.win[offPos];              // offset (2 bytes), match-length byte
-        const uint32_t off16 = ob & 0xffffu, b2 = (ob >> 16) & 0xffu;
-        const bool mlx = (t & 15u) == 15u;
-        const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
-        const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u);
-        bool ok = has && !(is15 && b1 == 255u) && !(mlx && b2 == 255u) && (int)nxt + 32 <= iendW && nxt <= PAR_WIN &&
-                  off16 != 0;
-        const int len = ok ? (int)(lit + ml) : 0;
-        const int incl = par_scan_incl(len);
-        const int outEnd = op + incl;
-        const int outStart = outEnd - len;
-        const int dpos = outStart + (int)lit;            // match destination
-        const int spos = dpos - (int)off16;              // match source
-        ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap && spos >= 0 &&
-             (spos >= ringBase || spos + (int)ml <= flushed);
-        const uint64_t okm = __ballot(ok);
-        const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
-        lap(PS_T_DECODE);
-        if (STATS) { sc[PS_BATCHES]++; sc[PS_SEQS] += (unsigned)nseq; if (nseq == LZ4_WAVE) sc[PS_FULL]++; }
-
-        if (nseq == 0) {
-            // not a plain interior sequence: the sequential decoder takes exactly one sequence
-            if (STATS) sc[PS_HANDOVERS]++;
-            flush(op, true);
-            st.ip = ip; st.op = op; st.fast = true;
-            const int r = decode_seq_run(st, 1, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
-            if (r != SEQ_CONTINUE) { lap(PS_T_SEQ); publish(); return r; }
-            ip = st.ip; op = st.op;
-            if (!st.fast || iend - ip < 64 || cap - op < 128) {
-                const int r2 = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
-                lap(PS_T_SEQ); publish();
-                return r2;
+            // ---------------- 3. chain: sequence r -> lane r ----------------
+            uint32_t c2 = (lane == 0) ? 2u * (uint32_t)wofs : (uint32_t)PAR_END;   // 2 x token position
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int d = 1 << k;
+                const int cj = (int)*(const uint16_t *)(jumpB + c2);
+                if (k < 5) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) J[j] = (uint32_t)*(const uint16_t *)(jumpB + J[j]);
+                }
+                int sh;
+                if (k == 0) sh = par_row_shr<1>(cj);
+                else if (k == 1) sh = par_row_shr<2>(cj);
+                else if (k == 2) sh = par_row_shr<4>(cj);
+                else if (k == 3) sh = par_row_shr<8>(cj);
+                else sh = par_bperm(cj, (lane - d) & 63);
+                if (lane >= d && lane < 2 * d) c2 = (uint32_t)sh;
+                if (k < 5) {
+                    wave_fence();
+                    *(uint4 *)&L.jump[8 * lane] =
+                        make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
+                    wave_fence();
+                }
             }
-            // reload the ring's history from global memory
+            lap(PS_T_CHAIN);
+
+            // ---------------- 4. decode own sequence, place it ----------------
+            const bool has = c2 < (uint32_t)PAR_END;
+            const uint32_t cc = has ? (c2 >> 1) : 0u;
+            const uint32_t tb = (uint32_t)(*(const par_u16u *)&L.win[cc]);      // token, next byte
+            const uint32_t t = tb & 0xffu, b1 = tb >> 8;
+            const bool is15 = (t >> 4) == 15u;
+            const uint32_t lit = is15 ? 15u + b1 : (t >> 4);
+            const uint32_t litStart = cc + 1u + (is15 ? 1u : 0u);
+            const uint32_t offPos = litStart + lit;                             // <= 511 + 272: inside the window
+            const uint32_t ob = *(const par_u32u *)&L.win[offPos];              // offset (2 bytes), match-length byte
+            const uint32_t off16 = ob & 0xffffu, b2 = (ob >> 16) & 0xffu;
+            const bool mlx = (t & 15u) == 15u;
+            const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
+            const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u);
+            bool ok = has && !(is15 && b1 == 255u) && !(mlx && b2 == 255u) && (int)nxt <= inLim && off16 != 0;
+            const int len = ok ? (int)(lit + ml) : 0;
+            const int incl = par_scan_incl(len);
+            const int outEnd = op + incl;
+            const int outStart = outEnd - len;
+            const int dpos = outStart + (int)lit;            // match destination
+            const int spos = dpos - (int)off16;              // match source
+            ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap && spos >= 0 &&
+                 (spos >= ringBase || spos + (int)ml <= flushed);
+            const uint64_t okm = __ballot(ok);
+            const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
+            lap(PS_T_DECODE);
+            if (STATS) { sc[PS_BATCHES]++; sc[PS_SEQS] += (unsigned)nseq; if (nseq == LZ4_WAVE) sc[PS_FULL]++; }
+            if (nseq == 0) break;                            // not a plain interior sequence: slow path below
+
+            const bool act = lane < nseq;
+            const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
+            const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
+            // prefetch the next window while this batch is copied
+            {
+                const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
+                wbase = nb;
+                wnext = fetch_window(nb);
+            }
+
+            const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
+            const bool nearSrc = spos >= ringBase;
+            const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
+            const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
+            const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups are safe
+
+            // ---------------- 5. far matches: source already in global memory ----------------
+            const uint64_t farm = __ballot(act && !nearSrc);
+            if (farm) {
+                if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
+                const uint8_t *gsrc = dst + spos;
+                const bool mine = act && !nearSrc;
+                // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
+                // past the match is written.  Far sources never overlap their destination.
+                const uint32_t step = (ml >= 8) ? 8u : 4u;
+                const uint32_t last = ml - step;
+                for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
+                    if (mine && base < ml) {
+                        if (step == 8) {
+                            uint64_t v[4];
+                            uint32_t o[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)(gsrc + o[k]); }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
+                        } else {
+                            const uint32_t v0 = *(const par_u32u *)(gsrc);
+                            const uint32_t v1 = *(const par_u32u *)(gsrc + last);
+                            *(par_u32u *)&L.ring[mdA] = v0;
+                            *(par_u32u *)&L.ring[mdA + last] = v1;
+                        }
+                    }
+                }
+            }
+
+            // ---------------- 6. literals: window -> ring ----------------
+            {
+                const uint32_t sA = litStart;
+                const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
+                const uint32_t n = act ? lit : 0u;
+                if (n >= 8) {
+                    const uint32_t last = n - 8;
+                    for (uint32_t o = 0;; o += 8) {
+                        const uint32_t oo = min(o, last);
+                        *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
+                        if (o >= last) break;
+                    }
+                } else if (n >= 4) {
+                    const uint32_t v0 = *(const par_u32u *)&L.win[sA], v1 = *(const par_u32u *)&L.win[sA + n - 4];
+                    *(par_u32u *)&L.ring[dA] = v0;
+                    *(par_u32u *)&L.ring[dA + n - 4] = v1;
+                } else if (n > 0) {
+                    const uint32_t v = *(const par_u32u *)&L.win[sA];
+                    L.ring[dA] = (uint8_t)v;
+                    if (n > 1) L.ring[dA + 1] = (uint8_t)(v >> 8);
+                    if (n > 2) L.ring[dA + 2] = (uint8_t)(v >> 16);
+                }
+            }
             wave_fence();
-            ringBase = (op > PAR_HIST) ? ((op - PAR_HIST) & ~15) : 0;
-            flushed = op;
-            for (int x = ringBase + lane; x < op; x += LZ4_WAVE) L.ring[x - ringBase + (int)A] = dst[x];
-            wave_fence();
-            lap(PS_T_SEQ);
-            continue;
-        }
+            lap(PS_T_LIT);
 
-        const bool act = lane < nseq;
-        const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
-        const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
-        // prefetch the next window while this batch is copied
-        {
-            const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
-            wbase = nb;
-            wnext = fetch_window(nb);
-        }
-
-        const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
-        const bool nearSrc = spos >= ringBase;
-        const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
-        const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
-        const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups are safe
-
-        // ---------------- 5. far matches: source already in global memory ----------------
-        uint64_t farm = __ballot(act && !nearSrc);
-        if (farm) {
-            if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
-            const uint8_t *gsrc = dst + spos;
-            const bool mine = act && !nearSrc;
-            // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
-            // past the match is written.  Far sources never overlap their destination.
-            const uint32_t step = (ml >= 8) ? 8u : 4u;
-            const uint32_t last = ml - step;
-            for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
-                if (mine && base < ml) {
-                    if (step == 8) {
+            // ---------------- 7. near matches: dependency rounds ----------------
+            uint64_t need = 0;
+            {
+                // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
+                const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
+                const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
+                int jlo = 0, jhi = 0;
+#pragma unroll
+                for (int stp = 32; stp >= 1; stp >>= 1) {
+                    const int c1 = jlo + stp, cb = jhi + stp;
+                    const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, cb & 63);
+                    if (c1 < nseq && v1 <= xlo) jlo = c1;
+                    if (cb < nseq && v2 <= xhi) jhi = cb;
+                }
+                if (act && nearSrc && srcHi > op && srcHi > spos) {
+                    const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
+                    need = upto & ~((1ull << jlo) - 1ull);
+                    need &= ~(1ull << lane);
+                    need &= ~farm;                                      // far matches are already in place
+                }
+            }
+            lap(PS_T_NEED);
+            uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
+            bool pending = act && nearSrc;                              // my match still has to be copied
+            const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
+            const uint32_t last8 = ml - 8;
+            while (~done) {
+                const bool mine = pending && ((need & ~done) == 0ull);
+                if (STATS) sc[PS_ROUNDS]++;
+                // lanes whose 32-byte groups never read their own writes: 4 x 8 bytes per step
+                for (uint32_t base = 0; __ballot(mine && grp && base < ml); base += 32) {
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    if (mine && grp && base < ml) {
                         uint64_t v[4];
                         uint32_t o[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)(gsrc + o[k]); }
+                        for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last8); v[k] = *(const par_u64u *)&L.ring[msA + o[k]]; }
 #pragma unroll
                         for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
-                    } else {
-                        const uint32_t v0 = *(const par_u32u *)(gsrc);
-                        const uint32_t v1 = *(const par_u32u *)(gsrc + last);
-                        *(par_u32u *)&L.ring[mdA] = v0;
-                        *(par_u32u *)&L.ring[mdA + last] = v1;
-                    }
-                }
-            }
-        }
-
-        // ---------------- 6. literals: window -> ring ----------------
-        {
-            const uint32_t sA = litStart;
-            const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
-            const uint32_t n = act ? lit : 0u;
-            if (n >= 8) {
-                const uint32_t last = n - 8;
-                for (uint32_t o = 0;; o += 8) {
-                    const uint32_t oo = min(o, last);
-                    *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
-                    if (o >= last) break;
-                }
-            } else if (n >= 4) {
-                const uint32_t v0 = *(const par_u32u *)&L.win[sA], v1 = *(const par_u32u *)&L.win[sA + n - 4];
-                *(par_u32u *)&L.ring[dA] = v0;
-                *(par_u32u *)&L.ring[dA + n - 4] = v1;
-            } else if (n > 0) {
-                const uint32_t v = *(const par_u32u *)&L.win[sA];
-                L.ring[dA] = (uint8_t)v;
-                if (n > 1) L.ring[dA + 1] = (uint8_t)(v >> 8);
-                if (n > 2) L.ring[dA + 2] = (uint8_t)(v >> 16);
-            }
-        }
-        wave_fence();
-        lap(PS_T_LIT);
-
-        // ---------------- 7. near matches: dependency rounds ----------------
-        uint64_t need = 0;
-        {
-            // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
-            const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
-            const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
-            int jlo = 0, jhi = 0;
-#pragma unroll
-            for (int stp = 32; stp >= 1; stp >>= 1) {
-                const int c1 = jlo + stp, c2 = jhi + stp;
-                const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, c2 & 63);
-                if (c1 < nseq && v1 <= xlo) jlo = c1;
-                if (c2 < nseq && v2 <= xhi) jhi = c2;
-            }
-            if (act && nearSrc && srcHi > op && srcHi > spos) {
-                const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
-                need = upto & ~((1ull << jlo) - 1ull);
-                need &= ~(1ull << lane);
-                need &= ~farm;                                      // far matches are already in place
-            }
-        }
-        lap(PS_T_NEED);
-        uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
-        const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
-        while (~done) {
-            const bool mine = !((done >> lane) & 1ull) && ((need & ~done) == 0ull);
-            if (STATS) sc[PS_ROUNDS]++;
-            // lanes whose 32-byte groups never read their own writes: 4 x 8 bytes per step
-            for (uint32_t base = 0; __ballot(mine && grp && base < ml); base += 32) {
-                if (STATS) sc[PS_MATCH_ITERS]++;
-                if (mine && grp && base < ml) {
-                    const uint32_t last = ml - 8;
-                    uint64_t v[4];
-                    uint32_t o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)&L.ring[msA + o[k]]; }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
-                }
-                wave_fence();
-            }
-            // short-offset lanes: 8- or 4-byte steps one after the other (a step may read the previous
-            // step's bytes); last chunk re-anchored at the end (idempotent rewrite)
-            if (__ballot(mine && !grp && (w8 || w4))) {
-                const uint32_t step = w8 ? 8u : 4u;
-                const uint32_t last = ml - step;
-                const bool wide = mine && !grp && (w8 || w4);
-                for (uint32_t o = 0; __ballot(wide && o < ml); o += step) {
-                    if (STATS) sc[PS_MATCH_ITERS]++;
-                    if (wide && o < ml) {
-                        const uint32_t oo = min(o, last);
-                        if (w8) *(par_u64u *)&L.ring[mdA + oo] = *(const par_u64u *)&L.ring[msA + oo];
-                        else *(par_u32u *)&L.ring[mdA + oo] = *(const par_u32u *)&L.ring[msA + oo];
                     }
                     wave_fence();
                 }
-            }
-            // offsets 1..3: byte steps
-            if (__ballot(mine && !w8 && !w4)) {
-                const bool slow = mine && !w8 && !w4;
-                for (uint32_t o = 0; __ballot(slow && o < ml); o++) {
-                    if (STATS) sc[PS_MATCH_ITERS]++;
-                    if (slow && o < ml) L.ring[mdA + o] = L.ring[msA + o];
-                    wave_fence();
+                // short offsets (rare): steps of 8 / 4 / 1 bytes one after the other, because a step may
+                // read the previous step's bytes; last chunk re-anchored at the end (idempotent rewrite)
+                if (__ballot(mine && !grp)) {
+                    const uint32_t step = w8 ? 8u : (w4 ? 4u : 1u);
+                    const uint32_t last = ml - step;
+                    const bool slow = mine && !grp;
+                    for (uint32_t o = 0; __ballot(slow && o < ml); o += step) {
+                        if (STATS) sc[PS_MATCH_ITERS]++;
+                        if (slow && o < ml) {
+                            const uint32_t oo = min(o, last);
+                            if (w8) *(par_u64u *)&L.ring[mdA + oo] = *(const par_u64u *)&L.ring[msA + oo];
+                            else if (w4) *(par_u32u *)&L.ring[mdA + oo] = *(const par_u32u *)&L.ring[msA + oo];
+                            else L.ring[mdA + oo] = L.ring[msA + oo];
+                        }
+                        wave_fence();
+                    }
                 }
+                pending = pending && !mine;
+                done |= __ballot(mine);
             }
-            done |= __ballot(mine);
-        }
-        wave_fence();
-        lap(PS_T_MATCH);
-
-        // ---------------- advance, 8. flush, slide ----------------
-        op = opNext;
-        ip = ipNext;
-        flush(op, false);
-        if (op - ringBase + (int)A + PAR_BATCH_OUT + 32 > PAR_RING) {
-            if (STATS) sc[PS_SLIDES]++;
-            const int newBase = (op - PAR_HIST) & ~15;
-            const int delta = newBase - ringBase;
-            const int n16 = (op - newBase + (int)A + 15) >> 4;
-            for (int k = lane; k < n16; k += LZ4_WAVE) {
-                const uint4 v = *(const uint4 *)&L.ring[delta + 16 * k];
-                wave_fence();
-                *(uint4 *)&L.ring[16 * k] = v;
-            }
-            ringBase = newBase;
             wave_fence();
-        }
-    }
+            lap(PS_T_MATCH);
 
-    // tail of the block (and every end-of-block rule) belongs to the sequential decoder
-    flush(op, true);
-    st.ip = ip; st.op = op; st.fast = true;
-    lap(PS_T_FLUSH);
-    const int rfin = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
-    lap(PS_T_SEQ);
-    publish();
-    return rfin;
+            // ---------------- advance, 8. flush, slide ----------------
+            op = opNext;
+            ip = ipNext;
+            flush(op, false);
+            if (op - ringBase + (int)A + PAR_BATCH_OUT + 32 > PAR_RING) {
+                if (STATS) sc[PS_SLIDES]++;
+                const int newBase = (op - PAR_HIST) & ~15;
+                const int delta = newBase - ringBase;
+                const int n16 = (op - newBase + (int)A + 15) >> 4;
+                for (int k = lane; k < n16; k += LZ4_WAVE) {
+                    const uint4 v = *(const uint4 *)&L.ring[delta + 16 * k];
+                    wave_fence();
+                    *(uint4 *)&L.ring[16 * k] = v;
+                }
+                ringBase = newBase;
+                wave_fence();
+            }
+        }
+
+        // ================= slow path: the sequential decoder =================
+        // Either a sequence the hot loop does not take (one sequence, then back), or the tail of the
+        // block (and with it every end-of-block rule and every error code).
+        flush(op, true);
+        st.ip = ip; st.op = op; st.fast = true;
+        const bool tail = (iend - ip < 64 || cap - op < 128);
+        if (STATS && !tail) sc[PS_HANDOVERS]++;
+        lap(PS_T_FLUSH);
+        int r = decode_seq_run(st, tail ? 0 : 1, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+        if (r == SEQ_CONTINUE && (!st.fast || iend - st.ip < 64 || cap - st.op < 128))
+            r = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+        lap(PS_T_SEQ);
+        if (r != SEQ_CONTINUE) { publish(); return r; }
+        ip = st.ip; op = st.op;
+        // reload the ring's history from global memory
+        wave_fence();
+        ringBase = (op > PAR_HIST) ? ((op - PAR_HIST) & ~15) : 0;
+        flushed = op;
+        for (int x = ringBase + lane; x < op; x += LZ4_WAVE) L.ring[x - ringBase + (int)A] = dst[x];
+        wave_fence();
+        lap(PS_T_SEQ);
+    }
 }
 
 } // namespace lz4dev

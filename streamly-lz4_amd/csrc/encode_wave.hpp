@@ -49,10 +49,55 @@ __device__ __forceinline__ uint8_t *emit_ext_len(uint8_t *op, uint32_t rest)
     return op + nff + 1;
 }
 
+// number of leading equal bytes (0..16) of two 16-byte groups
+__device__ __forceinline__ uint32_t common16(const uint4 &a, const uint4 &b)
+{
+    const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+    if (x0) return (uint32_t)__builtin_ctz(x0) >> 3;
+    if (x1) return 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+    if (x2) return 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+    if (x3) return 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+    return 16u;
+}
+
+__device__ __forceinline__ int par_free_bperm(int v, int srcLane)
+{
+    return __builtin_amdgcn_ds_bpermute(srcLane << 2, v);
+}
+
+__device__ __forceinline__ uint32_t ext_len_bytes(uint32_t len)   // bytes of the >= 15 continuation
+{
+    return (len >= 15u) ? 1u + (len - 15u) / 255u : 0u;
+}
+
+// inclusive wave scan (sum) with DPP
+__device__ __forceinline__ int enc_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
+// diagnostics (ENC_STATS builds only): cycles per phase of the dense-window path
+#ifdef ENC_STATS
+#define ENC_LAP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); est[i] += now_ - etm; etm = now_; } while (0)
+#else
+#define ENC_LAP(i) do { } while (0)
+#endif
+
 template <typename TabT>
-__device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int accel, TabT *table)
+__device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int accel, TabT *table,
+                                 unsigned long long *stats = nullptr)
 {
     const int lane = lane_id();
+#ifdef ENC_STATS
+    unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long etm = __builtin_amdgcn_s_memtime();
+#endif
     uint8_t *op = dst;
     int anchor = 0;
 
@@ -75,11 +120,229 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         const uint32_t miss0 = (uint32_t)accel << 6;
         uint32_t missAcc = miss0;
         int64_t p = 0;
+        uint64_t pfV8 = 0;          // dense path: this lane's 8 bytes of the window that starts at pfPos
+        int pfPos = -1;
 
         while (p < mfl) {
+            const int64_t step = (int64_t)(missAcc >> 6);
+            if (step == 1) {
+                // ===== dense window (acceleration 1, no miss streak): 64 consecutive positions, and EVERY
+                // match found in the window is emitted in this iteration, not only the first =====
+                const int p0 = (int)p;
+                const int myPos = p0 + lane;
+                const bool valid = myPos < mfl;
+                uint32_t h = 0, cand = 0, myMl = 0;
+                uint64_t v8 = 0;
+                bool candOk = false;
+                if (valid) {
+                    v8 = (pfPos == p0) ? pfV8 : *(const u64_unaligned *)(src + myPos);
+                    h = hash5(v8);
+                    cand = (uint32_t)table[h];
+                    candOk = cand < (uint32_t)myPos && (uint32_t)myPos - cand <= LZ4_MAXDIST;   // :1003-1006
+                }
+                ENC_LAP(0);
+                // Candidates of neighbouring positions that are themselves neighbours (cand[l] == cand[l-1]+1)
+                // belong to one copied region: only the HEAD of such a run reads its candidate and counts
+                // bytes (:1009, LZ4_count :603-626); the others derive hit and length from it.  This keeps
+                // the scattered candidate loads to roughly one per real match plus the unmatched positions.
+                bool hit = false;
+                uint32_t hback = 0;       // head only: equal bytes just before the match (catch up, :1019), 0..8
+                int myHead = 0;
+                {
+                    const uint32_t prevCand = (uint32_t)__shfl_up((int)(candOk ? cand : 0xffffffffu), 1);
+                    const bool contin = candOk && lane > 0 && prevCand != 0xffffffffu && cand == prevCand + 1u;
+                    const bool head = candOk && !contin;
+                    if (head) {
+                        // one scattered request: the 8 bytes before the candidate (catch up) and the 8 at it
+                        uint64_t c8, a8 = 0, b8 = 1;
+                        if (cand >= 8u) {
+                            uint4 bc;
+                            __builtin_memcpy(&bc, src + cand - 8, 16);
+                            b8 = ((uint64_t)bc.y << 32) | bc.x;
+                            c8 = ((uint64_t)bc.w << 32) | bc.z;
+                            a8 = *(const u64_unaligned *)(src + myPos - 8);
+                        } else {
+                            c8 = *(const u64_unaligned *)(src + cand);
+                        }
+                        const uint64_t x = v8 ^ c8;
+                        if ((uint32_t)x == 0) {                                  // 4 equal bytes
+                            hit = true;
+                            const uint64_t xb = a8 ^ b8;
+                            hback = (cand >= 8u) ? (xb ? ((uint32_t)__builtin_clzll(xb) >> 3) : 8u) : 0u;
+                            const uint32_t maxLen = (uint32_t)(matchlimit - myPos);   // >= 7
+                            uint32_t m = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
+                            if (m == 8u) {
+                                bool more = true;
+                                while (more && m + 32u <= maxLen) {               // 32 bytes a step
+                                    uint4 a0, a1, b0, b1;
+                                    __builtin_memcpy(&a0, src + myPos + m, 16);
+                                    __builtin_memcpy(&a1, src + myPos + m + 16, 16);
+                                    __builtin_memcpy(&b0, src + cand + m, 16);
+                                    __builtin_memcpy(&b1, src + cand + m + 16, 16);
+                                    uint32_t d = common16(a0, b0);
+                                    if (d == 16u) d += common16(a1, b1);
+                                    m += d;
+                                    more = (d == 32u);
+                                }
+                                while (more && m + 16u <= maxLen) {
+                                    uint4 a0, b0;
+                                    __builtin_memcpy(&a0, src + myPos + m, 16);
+                                    __builtin_memcpy(&b0, src + cand + m, 16);
+                                    const uint32_t d = common16(a0, b0);
+                                    m += d;
+                                    more = (d == 16u);
+                                }
+                                while (more && m < maxLen && src[myPos + m] == src[cand + m]) m++;
+                            }
+                            myMl = min(m, maxLen);
+                        }
+                    }
+                    const uint64_t headm = __ballot(head);
+#ifdef ENC_STATS
+                    est[7] += (unsigned)__builtin_popcountll(headm);
+#endif
+                    const uint64_t below = headm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                    myHead = below ? 63 - (int)__builtin_clzll(below) : 0;
+                    const int headInfo = par_free_bperm((int)(myMl | (hback << 16)), myHead);   // 0 when the head missed
+                    if (contin) {
+                        const int m = (headInfo & 0xffff) - (lane - myHead);
+                        hit = m >= LZ4_MINMATCH;
+                        myMl = hit ? (uint32_t)m : 0u;
+                        hback = (uint32_t)headInfo >> 16;
+                    }
+                }
+                ENC_LAP(1);
+                // ---- greedy left-to-right selection of non-overlapping matches ----
+                uint64_t hitm = __ballot(hit);
+                if (!hitm) {
+                    if (valid) table[h] = (TabT)myPos;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    missAcc += LZ4_WAVE;
+                    p += LZ4_WAVE;
+                    pfPos = -1;
+                    continue;
+                }
+                uint64_t selm = 0;
+                int prevEnd = anchor;            // per lane: end of the previous selected match (my literal start)
+                bool covered = false;            // my position lies strictly inside a selected match
+                int pEnd = anchor;
+                while (hitm) {
+                    const int k = (int)__builtin_ctzll(hitm);
+                    const int endk = p0 + k + (int)__builtin_amdgcn_readlane((int)myMl, k);
+                    selm |= 1ull << k;
+                    if (lane == k) prevEnd = pEnd;
+                    covered = covered || (lane > k && myPos < endk);
+                    pEnd = endk;
+                    const int sh = endk - p0;
+                    hitm = (sh >= LZ4_WAVE) ? 0ull : (hitm & (~0ull << sh));
+                }
+                const int lastEnd = pEnd;
+                const bool sel = (selm >> lane) & 1ull;
+                // the next window starts at lastEnd: fetch its bytes now, under the emit below
+                pfPos = lastEnd;
+                pfV8 = (lastEnd + lane < mfl) ? *(const u64_unaligned *)(src + lastEnd + lane) : 0ull;
+                ENC_LAP(2);
+                // ---- table: the probed positions outside the selected matches (:998) ----
+                if (valid && !covered && myPos < lastEnd) table[h] = (TabT)myPos;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int myEnd = myPos + (int)myMl;
+                ENC_LAP(3);
+                // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
+                // are known equal, the head measured up to 8 more before itself ----
+                int mstart = myPos, mcand = (int)cand;
+                if (sel) {
+                    const int room = min(mstart - prevEnd, mcand);
+                    const int back = min(room, (lane - myHead) + (int)hback);
+                    mstart -= back; mcand -= back;
+                }
+                ENC_LAP(4);
+                // ---- sizes, output offsets ----
+                const uint32_t lit = sel ? (uint32_t)(mstart - prevEnd) : 0u;
+                const uint32_t mlen = sel ? (uint32_t)(myEnd - mstart) : 0u;
+                const uint32_t mc = mlen - LZ4_MINMATCH;
+                const uint32_t esz = sel ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
+                const int incl = enc_scan_incl((int)esz);
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                uint8_t *o = op + (incl - (int)esz);
+                // ---- emit (:1022-1046, :1065-1135): every selected lane writes its own sequence ----
+                if (sel) {
+                    *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
+                    if (lit >= 15u) {
+                        uint32_t rest = lit - 15u;
+                        while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+                        *o++ = (uint8_t)rest;
+                    }
+                }
+                uint8_t *litDst = o;
+                // literals that lie inside this window are taken from the lanes' registers (lane q-p0 holds
+                // bytes [q, q+8)); only a run that starts before the window goes back to memory
+                const bool fromRegs = sel && lit <= 32u && prevEnd >= p0;
+                {
+                    const int lo32 = (int)(uint32_t)v8, hi32 = (int)(uint32_t)(v8 >> 32);
+                    const uint32_t last = (lit >= 8u) ? lit - 8u : 0u;
+                    for (uint32_t q = 0; __ballot(fromRegs && q < max(lit, 1u) && lit > 0u); q += 8u) {
+                        const uint32_t qq = min(q, last);
+                        const int sl = (prevEnd - p0 + (int)qq) & 63;
+                        const uint32_t wl = (uint32_t)par_free_bperm(lo32, sl), wh = (uint32_t)par_free_bperm(hi32, sl);
+                        if (fromRegs && q < lit) {
+                            if (lit >= 8u) {
+                                *(u64_unaligned *)(litDst + qq) = ((uint64_t)wh << 32) | wl;
+                            } else {
+                                uint64_t w = ((uint64_t)wh << 32) | wl;
+                                uint32_t done = 0;
+                                if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
+                                for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
+                            }
+                        }
+                    }
+                }
+                if (sel) {
+                    if (!fromRegs && lit <= 32u) {              // short run from before the window: its own lane
+                        const uint8_t *litSrc = src + prevEnd;
+                        if (lit >= 8u) {
+                            const uint32_t last = lit - 8u;
+                            for (uint32_t q = 0;; q += 8u) {
+                                const uint32_t qq = min(q, last);
+                                *(u64_unaligned *)(litDst + qq) = *(const u64_unaligned *)(litSrc + qq);
+                                if (q >= last) break;
+                            }
+                        } else {
+                            for (uint32_t q = 0; q < lit; q++) litDst[q] = litSrc[q];
+                        }
+                    }
+                    o += lit;
+                    const uint32_t off = (uint32_t)(mstart - mcand);
+                    o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8);
+                    o += 2;
+                    if (mc >= 15u) {
+                        uint32_t rest = mc - 15u;
+                        while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+                        *o++ = (uint8_t)rest;
+                    }
+                }
+                // long literal runs are copied by the whole wave
+                for (uint64_t lm = __ballot(sel && lit > 32u); lm; lm &= lm - 1) {
+                    const int k = (int)__builtin_ctzll(lm);
+                    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
+                    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
+                    uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
+                    const int s0 = __builtin_amdgcn_readlane(prevEnd, k);
+                    const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
+                    wave_copy_bytes(d, src + s0, ln);
+                }
+                op += total;
+                anchor = lastEnd;
+                p = lastEnd;
+                missAcc = miss0;
+                ENC_LAP(5);
+#ifdef ENC_STATS
+                est[6] += 1;
+#endif
+                continue;
+            }
+            // ===== strided window (acceleration > 1 or after a miss streak): first match only =====
             // probe positions p, p+1, p+2, then every `step`: like the reference, which probes
             // ip, ip+1, ip+2 after each match before its stride takes over (:1159, :1200, :956-967)
-            const int64_t step = (int64_t)(missAcc >> 6);
             const int64_t myPos64 = p + (lane < 3 ? (int64_t)lane : 2 + (int64_t)(lane - 2) * step);
             const bool valid = myPos64 < (int64_t)mfl;
             const int myPos = valid ? (int)myPos64 : 0;
@@ -155,6 +418,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         }
     }
 
+#ifdef ENC_STATS
+    if (stats && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stats[i], est[i]);
+#endif
     // ---- last literals (:1204-1231) ----
     {
         const uint32_t lastRun = (uint32_t)(n - anchor);

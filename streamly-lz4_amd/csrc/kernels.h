@@ -40,6 +40,7 @@ struct EncodeArgs {
     uint8_t *slots;
     size_t slotStride;
     int32_t *framedLen;
+    unsigned long long *stats;   // diagnostics only (ENC_STATS builds); may be null
 };
 
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);

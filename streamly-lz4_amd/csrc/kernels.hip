@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
     uint8_t *slot = a.slots + (size_t)blk * a.slotStride;
     int c = 0;
     if (n >= 0 && (sizeof(TabT) == 4 || n <= 65536))
-        c = encode_block_wave<TabT>(a.src + off, n, slot + a.headerKind, a.accel, table);
+        c = encode_block_wave<TabT>(a.src + off, n, slot + a.headerKind, a.accel, table, a.stats);
     if (lane_id() == 0) {
         store_le32(slot, c);                                   // Internal/LZ4.hs:262
         if (a.headerKind == 8) store_le32(slot + 4, n);        // Internal/LZ4.hs:261
