@@ -61,19 +61,26 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
+    # BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only to rehearse the N>1 code path on a 1-GPU box
+    # (all ranks on one device, gloo rendezvous); the driver's launch uses one GPU per rank over RCCL.
+    dev_index = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the timing reduction lives
 
     kind, BL, NB, accel, phase = WORKLOADS[args.workload]
     if args.blocks:
         NB = args.blocks
-    eng = S.Engine(local_rank)
+    eng = S.Engine(dev_index)
     eng.set_decoder(args.decoder)
 
     # ---- setup (untimed): generate this rank's blocks on the device, compress, compact ----
@@ -144,7 +151,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)

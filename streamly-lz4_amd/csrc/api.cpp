@@ -152,7 +152,7 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -248,10 +248,12 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.headerKind = headerKind; a.fixedUncomp = fixedUncomp; a.linked = linked ? 1 : 0;
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
-    if (c->decoder != 1)
-        launch_decode_par(a, c->stats, c->stream);
-    else
+    if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
+    else if (c->decoder == 3)
+        launch_decode_par2(a, c->stream);
+    else
+        launch_decode_par(a, c->stats, c->stream);
     if (linked) launch_decode_fixup_linked(a, c->stream);
     return check_launch("decode launch");
 }

@@ -65,6 +65,26 @@ typedef uint64_t par_u64u __attribute__((aligned(1)));
 typedef uint32_t par_u32u __attribute__((aligned(1)));
 typedef uint16_t par_u16u __attribute__((aligned(1)));
 
+typedef uint32_t par_v4 __attribute__((ext_vector_type(4)));
+typedef par_v4 par_v4u __attribute__((aligned(1)));      // one ds_read/write_b128 at any byte address
+
+// LDS cost model on gfx950 (measured, scripts/micro/lds_unaligned.hip): a naturally aligned access costs
+// ~6 cycles per wave-instruction; an access that is NOT naturally aligned costs ~1 cycle PER ACTIVE LANE,
+// whatever its width (4, 8 or 16 bytes).  Hence: fields are fetched with aligned dword reads + a byte
+// funnel (v_alignbyte), and byte-granular copies use the widest chunk that is safe.
+__device__ __forceinline__ uint32_t lds_u32_any(const uint8_t *base4, uint32_t addr)
+{
+    const uint32_t *p = (const uint32_t *)(base4 + (addr & ~3u));
+    return __builtin_amdgcn_alignbyte(p[1], p[0], addr & 3u);
+}
+__device__ __forceinline__ uint64_t lds_u64_any(const uint8_t *base4, uint32_t addr)
+{
+    const uint32_t *p = (const uint32_t *)(base4 + (addr & ~3u));
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const uint32_t sh = addr & 3u;
+    return ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+}
+
 __device__ __forceinline__ int par_bperm(int v, int srcLane)
 {
     return __builtin_amdgcn_ds_bpermute(srcLane << 2, v);
@@ -242,13 +262,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // ---------------- 4. decode own sequence, place it ----------------
             const bool has = c2 < (uint32_t)PAR_END;
             const uint32_t cc = has ? (c2 >> 1) : 0u;
-            const uint32_t tb = (uint32_t)(*(const par_u16u *)&L.win[cc]);      // token, next byte
-            const uint32_t t = tb & 0xffu, b1 = tb >> 8;
+            const uint32_t tb = lds_u32_any(L.win, cc);                          // token, next byte
+            const uint32_t t = tb & 0xffu, b1 = (tb >> 8) & 0xffu;
             const bool is15 = (t >> 4) == 15u;
             const uint32_t lit = is15 ? 15u + b1 : (t >> 4);
             const uint32_t litStart = cc + 1u + (is15 ? 1u : 0u);
             const uint32_t offPos = litStart + lit;                             // <= 511 + 272: inside the window
-            const uint32_t ob = *(const par_u32u *)&L.win[offPos];              // offset (2 bytes), match-length byte
+            const uint32_t ob = lds_u32_any(L.win, offPos);                      // offset (2 bytes), match-length byte
             const uint32_t off16 = ob & 0xffffu, b2 = (ob >> 16) & 0xffu;
             const bool mlx = (t & 15u) == 15u;
             const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
@@ -282,9 +302,37 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool nearSrc = spos >= ringBase;
             const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
             const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
-            const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups are safe
+            const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups never read their own writes
+            const bool g16 = grp && ml >= 16;                       // ... as two 16-byte chunks
+            const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
 
-            // ---------------- 5. far matches: source already in global memory ----------------
+            // ---------------- 5. literals: window -> ring ----------------
+            {
+                const uint32_t sA = litStart;
+                const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
+                const uint32_t n = act ? lit : 0u;
+                if (n > 8) {                                    // rare (token nibble 15 or close to it)
+                    const uint32_t last = n - 8;
+                    for (uint32_t o = 0;; o += 8) {
+                        const uint32_t oo = min(o, last);
+                        *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
+                        if (o >= last) break;
+                    }
+                } else if (n > 0) {
+                    const uint64_t v = lds_u64_any(L.win, sA);  // aligned reads + funnel
+                    if (n + ml >= 8) {
+                        // one 8-byte store; the bytes past the literals fall into my own match area, which is
+                        // written afterwards (steps 6 and 7)
+                        *(par_u64u *)&L.ring[dA] = v;
+                    } else {
+                        uint64_t w = v;
+                        for (uint32_t q = 0; q < n; q++) { L.ring[dA + q] = (uint8_t)w; w >>= 8; }
+                    }
+                }
+            }
+            wave_fence();
+
+            // ---------------- 6. far matches: source already in global memory ----------------
             const uint64_t farm = __ballot(act && !nearSrc);
             if (farm) {
                 if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
@@ -292,17 +340,21 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const bool mine = act && !nearSrc;
                 // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
                 // past the match is written.  Far sources never overlap their destination.
-                const uint32_t step = (ml >= 8) ? 8u : 4u;
+                const uint32_t step = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
                 const uint32_t last = ml - step;
                 for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
                     if (mine && base < ml) {
-                        if (step == 8) {
-                            uint64_t v[4];
-                            uint32_t o[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last); v[k] = *(const par_u64u *)(gsrc + o[k]); }
-#pragma unroll
-                            for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
+                        if (step == 16) {
+                            const uint32_t o0 = min(base, last), o1 = min(base + 16u, last);
+                            par_v4 v0, v1;
+                            __builtin_memcpy(&v0, gsrc + o0, 16);
+                            __builtin_memcpy(&v1, gsrc + o1, 16);
+                            *(par_v4u *)&L.ring[mdA + o0] = v0;
+                            *(par_v4u *)&L.ring[mdA + o1] = v1;
+                        } else if (step == 8) {
+                            const uint64_t v0 = *(const par_u64u *)(gsrc), v1 = *(const par_u64u *)(gsrc + last);
+                            *(par_u64u *)&L.ring[mdA] = v0;
+                            *(par_u64u *)&L.ring[mdA + last] = v1;
                         } else {
                             const uint32_t v0 = *(const par_u32u *)(gsrc);
                             const uint32_t v1 = *(const par_u32u *)(gsrc + last);
@@ -312,32 +364,6 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     }
                 }
             }
-
-            // ---------------- 6. literals: window -> ring ----------------
-            {
-                const uint32_t sA = litStart;
-                const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
-                const uint32_t n = act ? lit : 0u;
-                if (n >= 8) {
-                    const uint32_t last = n - 8;
-                    for (uint32_t o = 0;; o += 8) {
-                        const uint32_t oo = min(o, last);
-                        *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
-                        if (o >= last) break;
-                    }
-                } else if (n >= 4) {
-                    const uint32_t v0 = *(const par_u32u *)&L.win[sA], v1 = *(const par_u32u *)&L.win[sA + n - 4];
-                    *(par_u32u *)&L.ring[dA] = v0;
-                    *(par_u32u *)&L.ring[dA + n - 4] = v1;
-                } else if (n > 0) {
-                    const uint32_t v = *(const par_u32u *)&L.win[sA];
-                    L.ring[dA] = (uint8_t)v;
-                    if (n > 1) L.ring[dA + 1] = (uint8_t)(v >> 8);
-                    if (n > 2) L.ring[dA + 2] = (uint8_t)(v >> 16);
-                }
-            }
-            wave_fence();
-            lap(PS_T_LIT);
 
             // ---------------- 7. near matches: dependency rounds ----------------
             uint64_t need = 0;
@@ -368,16 +394,25 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             while (~done) {
                 const bool mine = pending && ((need & ~done) == 0ull);
                 if (STATS) sc[PS_ROUNDS]++;
-                // lanes whose 32-byte groups never read their own writes: 4 x 8 bytes per step
-                for (uint32_t base = 0; __ballot(mine && grp && base < ml); base += 32) {
+                // lanes whose 32-byte groups never read their own writes: 2 x 16 bytes per step
+                for (uint32_t base = 0; __ballot(mine && g16 && base < ml); base += 32) {
                     if (STATS) sc[PS_MATCH_ITERS]++;
-                    if (mine && grp && base < ml) {
-                        uint64_t v[4];
-                        uint32_t o[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { o[k] = min(base + 8u * k, last8); v[k] = *(const par_u64u *)&L.ring[msA + o[k]]; }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) *(par_u64u *)&L.ring[mdA + o[k]] = v[k];
+                    if (mine && g16 && base < ml) {
+                        const uint32_t last16 = ml - 16;
+                        const uint32_t o0 = min(base, last16), o1 = min(base + 16u, last16);
+                        const par_v4 v0 = *(const par_v4u *)&L.ring[msA + o0];
+                        const par_v4 v1 = *(const par_v4u *)&L.ring[msA + o1];
+                        *(par_v4u *)&L.ring[mdA + o0] = v0;
+                        *(par_v4u *)&L.ring[mdA + o1] = v1;
+                    }
+                    wave_fence();
+                }
+                if (__ballot(mine && g8)) {                                 // 8 <= ml < 16: two 8-byte chunks
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    if (mine && g8) {
+                        const uint64_t v0 = *(const par_u64u *)&L.ring[msA], v1 = *(const par_u64u *)&L.ring[msA + last8];
+                        *(par_u64u *)&L.ring[mdA] = v0;
+                        *(par_u64u *)&L.ring[mdA + last8] = v1;
                     }
                     wave_fence();
                 }

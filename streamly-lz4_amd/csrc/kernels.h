@@ -47,6 +47,7 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
+void launch_decode_par2(const DecodeArgs &a, hipStream_t s);
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
                     uint8_t *dense, uint64_t *denseOff, hipStream_t s);

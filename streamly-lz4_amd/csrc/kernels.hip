@@ -11,6 +11,7 @@
 
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
+#include "decode_par2.hpp"
 #include "encode_wave.hpp"
 
 using namespace lz4dev;
@@ -328,4 +329,31 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
         hipLaunchKernelGGL(k_decode_par<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
     else
         hipLaunchKernelGGL(k_decode_par<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+}
+
+// Two-wave lane-parallel decoder (decode_par2.hpp): one 128-thread workgroup per block,
+// wave 0 parses batch b+1 while wave 1 copies batch b.
+__global__ __launch_bounds__(128, P2_WAVES) void k_decode_par2(DecodeArgs a)
+{
+    __shared__ Par2Lds lds;
+    const int blk = (int)blockIdx.x;
+    const int role = uni((int)(threadIdx.x >> 6));
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = read_block_header(a, blk, data, compLen, cap);
+    if (r == 0) {
+        uint8_t *dst = a.out + a.outOff[blk];
+        if (cap < 128 || compLen < 64) {
+            if (role == 1) r = decode_block_seq(data, compLen, dst, cap, nullptr, 0, a.framed, a.framed + a.framedLen);
+        } else {
+            r = decode_block_par2(role, data, compLen, dst, cap, a.framed, a.framed + a.framedLen, lds);
+        }
+    }
+    if (role == 1 && lane_id() == 0) a.result[blk] = r;
+}
+
+void launch_decode_par2(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    hipLaunchKernelGGL(k_decode_par2, dim3((unsigned)a.nBlocks), dim3(128), 0, s, a);
 }
