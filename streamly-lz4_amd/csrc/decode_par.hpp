@@ -306,6 +306,27 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool g16 = grp && ml >= 16;                       // ... as two 16-byte chunks
             const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
 
+            // ---------------- dependency masks (independent of the copies below: issued first so that
+            // their cross-lane traffic overlaps the literal and far copies) ----------------
+            uint64_t need = 0;
+            {
+                // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
+                const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
+                const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
+                int jlo = 0, jhi = 0;
+#pragma unroll
+                for (int stp = 32; stp >= 1; stp >>= 1) {
+                    const int c1 = jlo + stp, cb = jhi + stp;
+                    const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, cb & 63);
+                    if (c1 < nseq && v1 <= xlo) jlo = c1;
+                    if (cb < nseq && v2 <= xhi) jhi = cb;
+                }
+                if (act && nearSrc && srcHi > op && srcHi > spos) {
+                    const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
+                    need = upto & ~((1ull << jlo) - 1ull);
+                    need &= ~(1ull << lane);
+                }
+            }
             // ---------------- 5. literals: window -> ring ----------------
             {
                 const uint32_t sA = litStart;
@@ -366,27 +387,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             }
 
             // ---------------- 7. near matches: dependency rounds ----------------
-            uint64_t need = 0;
-            {
-                // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
-                const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
-                const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
-                int jlo = 0, jhi = 0;
-#pragma unroll
-                for (int stp = 32; stp >= 1; stp >>= 1) {
-                    const int c1 = jlo + stp, cb = jhi + stp;
-                    const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, cb & 63);
-                    if (c1 < nseq && v1 <= xlo) jlo = c1;
-                    if (cb < nseq && v2 <= xhi) jhi = cb;
-                }
-                if (act && nearSrc && srcHi > op && srcHi > spos) {
-                    const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
-                    need = upto & ~((1ull << jlo) - 1ull);
-                    need &= ~(1ull << lane);
-                    need &= ~farm;                                      // far matches are already in place
-                }
-            }
             lap(PS_T_NEED);
+            need &= ~farm;                                              // far matches are already in place
             uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
             bool pending = act && nearSrc;                              // my match still has to be copied
             const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;

@@ -308,8 +308,13 @@ void launch_generate(int kind, uint8_t *dst, int blockLen, int nBlocks, uint64_t
 }
 
 // Lane-parallel decoder (decode_par.hpp): one wavefront (= one workgroup) per block.
+#ifdef PAR_WAVES_MAX
+#define PAR_OCC __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(PAR_WAVES, PAR_WAVES_MAX)))
+#else
+#define PAR_OCC __launch_bounds__(64, PAR_WAVES)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64, PAR_WAVES) void k_decode_par(DecodeArgs a, unsigned long long *stats)
+__global__ PAR_OCC void k_decode_par(DecodeArgs a, unsigned long long *stats)
 {
     __shared__ ParLds lds;
     const int blk = (int)blockIdx.x;

@@ -84,11 +84,30 @@ struct InWindow {
     }
 };
 
-// Wave-parallel byte copy, non-overlapping (literals: compressed stream -> output).
+// Wave-parallel byte copy, non-overlapping (literal runs: compressed stream <-> raw bytes).
+// Long runs (incompressible data is one run per block) move 16 bytes per lane with aligned
+// stores; short runs one byte per lane.
 __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
 {
+    const uint32_t lane = (uint32_t)lane_id();
+    if (n >= 512u) {
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+        if (lane < head) dst[lane] = src[lane];
+        const uint32_t body = (n - head) >> 4;
+        uint4 *d16 = (uint4 *)(dst + head);
+        const uint8_t *s16 = src + head;
 #pragma unroll 2
-    for (uint32_t i = (uint32_t)lane_id(); i < n; i += LZ4_WAVE) dst[i] = src[i];
+        for (uint32_t i = lane; i < body; i += LZ4_WAVE) {
+            uint4 v;
+            __builtin_memcpy(&v, s16 + ((size_t)i << 4), 16);     // unaligned 16-byte load
+            d16[i] = v;
+        }
+        const uint32_t done = head + (body << 4);
+        if (done + lane < n) dst[done + lane] = src[done + lane];
+        return;
+    }
+#pragma unroll 2
+    for (uint32_t i = lane; i < n; i += LZ4_WAVE) dst[i] = src[i];
 }
 
 } // namespace lz4dev
