@@ -80,6 +80,53 @@ static int pin_reserve(DevBuf &b, size_t bytes)
 static void dev_release(DevBuf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
 static void pin_release(DevBuf &b) { if (b.p) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
 
+// ---------------------------------------------------------------------------
+// Host <-> device transfers of pageable memory, pipelined through pinned staging:
+// the CPU memcpy of chunk i+1 overlaps the DMA of chunk i.
+// A plain hipMemcpy of pageable memory runs at a few GB/s; this keeps the link busy.
+// ---------------------------------------------------------------------------
+static const size_t kStageChunk = (size_t)8 << 20;
+
+static int h2d_staged(mi355lz4_ctx *c, void *dstDev, const uint8_t *srcHost, size_t bytes)
+{
+    if (!bytes) return 0;
+    int r = pin_reserve(c->pinIn, bytes);
+    if (r) return r;
+    uint8_t *stage = (uint8_t *)c->pinIn.p;
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
+        memcpy(stage + off, srcHost + off, n);
+        HIP_TRY(hipMemcpyAsync((uint8_t *)dstDev + off, stage + off, n, hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+
+static int d2h_staged(mi355lz4_ctx *c, uint8_t *dstHost, const void *srcDev, size_t bytes)
+{
+    if (!bytes) return 0;
+    int r = pin_reserve(c->pinOut, bytes);
+    if (r) return r;
+    uint8_t *stage = (uint8_t *)c->pinOut.p;
+    const size_t nChunks = (bytes + kStageChunk - 1) / kStageChunk;
+    std::vector<hipEvent_t> ev(nChunks);
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t off = k * kStageChunk;
+        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
+        HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(stage + off, (const uint8_t *)srcDev + off, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(ev[k], c->stream));
+    }
+    int rc = 0;
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t off = k * kStageChunk;
+        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
+        if (!rc && hipEventSynchronize(ev[k]) != hipSuccess) rc = fail(MI355LZ4_E_HIP, "hipEventSynchronize failed");
+        if (!rc) memcpy(dstHost + off, stage + off, n);
+        hipEventDestroy(ev[k]);
+    }
+    return rc;
+}
+
 static bool device_is_gfx950(int dev)
 {
     hipDeviceProp_t prop;
@@ -380,9 +427,17 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
     if ((r = dev_reserve(c->offB, ((size_t)nBlocks + 1) * 8))) return r;
 
     uint8_t *stage = (uint8_t *)c->pinIn.p;
-    for (int i = 0; i < nBlocks; i++)
-        if (srcLen[i] > 0) memcpy(stage + offs[(size_t)i], src[i], (size_t)srcLen[i]);
-    HIP_TRY(hipMemcpyAsync(c->in.p, stage, total, hipMemcpyHostToDevice, c->stream));
+    {
+        size_t sent = 0;                       // staging bytes already handed to the DMA engine
+        for (int i = 0; i < nBlocks; i++) {
+            if (srcLen[i] > 0) memcpy(stage + offs[(size_t)i], src[i], (size_t)srcLen[i]);
+            const size_t filled = (i + 1 < nBlocks) ? (size_t)offs[(size_t)i + 1] : total;
+            if (filled - sent >= kStageChunk || i + 1 == nBlocks) {
+                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + sent, stage + sent, filled - sent, hipMemcpyHostToDevice, c->stream));
+                sent = filled;
+            }
+        }
+    }
     HIP_TRY(hipMemcpyAsync(c->offA.p, offs.data(), (size_t)nBlocks * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->lenA.p, srcLen, (size_t)nBlocks * 4, hipMemcpyHostToDevice, c->stream));
     // offs / srcLen are pageable: make sure the copies have consumed them before they go away
@@ -411,8 +466,7 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
     }
     if (bad) return fail(MI355LZ4_E_BLOCK, "compress_batch: %d block(s) failed", bad);
     if (totalOut > cap) return fail(MI355LZ4_E_CAPACITY, "compress_batch: need %llu bytes, have %zu", (unsigned long long)totalOut, cap);
-    HIP_TRY(hipMemcpyAsync(framedOut, c->dense.p, (size_t)totalOut, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = d2h_staged(c, framedOut, c->dense.p, (size_t)totalOut))) return r;
     *outLen = (size_t)totalOut;
     return MI355LZ4_OK;
 }
@@ -483,7 +537,7 @@ extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedI
         if ((r = dev_reserve(c->scratch, 65536 + 16))) return r;
         HIP_TRY(hipMemcpyAsync(c->scratch.p, dict + (dictLen - (int)dlen), dlen, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->in.p, framedIn, inLen, hipMemcpyHostToDevice, c->stream));
+    if ((r = h2d_staged(c, c->in.p, framedIn, inLen))) return r;
     HIP_TRY(hipMemcpyAsync(c->offA.p, boff.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->offB.p, ooff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -506,7 +560,7 @@ extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedI
     if (bad) return fail(MI355LZ4_E_BLOCK, "decompress_batch: %d block(s) failed", bad);
     if (need > cap) return fail(MI355LZ4_E_CAPACITY, "decompress_batch: need %llu bytes, have %zu", (unsigned long long)need, cap);
     if (need == total) {
-        HIP_TRY(hipMemcpyAsync(out, c->out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        if ((r = d2h_staged(c, out, c->out.p, (size_t)total))) return r;
     } else {
         uint64_t w = 0;
         for (int i = 0; i < n; i++) {
