@@ -376,3 +376,69 @@ def test_roundtrip_config5_random_256k(slz4, engine):
 
 def test_roundtrip_text(slz4, engine):
     _roundtrip_device(slz4, engine, "text", 8192, 65536, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# ragged batches and large blocks (reference edge cases: empty / ragged arrays, BlockMax4MB)
+# --------------------------------------------------------------------------------------------
+def test_ragged_batch_roundtrip(engine, oracle):
+    rng = random.Random(77)
+    blocks = []
+    for i in range(120):
+        kind = rng.choice(["lzsynth", "text", "random"])
+        n = rng.choice([0, 1, 2, 11, 12, 13, 14, 100, 127, 128, 129, 1000, 4095, 4096, 65535, 65536, 65537, 200000])
+        n = max(0, n + rng.randrange(-3, 4)) if n > 20 else n
+        blocks.append(oracle.gen(kind, 1, max(n, 1), first_block=1000 + i)[:n].tobytes())
+    fr, flen = engine.compress_batch(blocks, accel=1)
+    # every block decodes standalone with the oracle, bit-exact
+    pos = 0
+    for b, f in zip(blocks, flen):
+        assert int.from_bytes(fr[pos + 4:pos + 8], "little") == len(b)
+        assert oracle.decompress_block(fr[pos + 8:pos + f], len(b)) == (len(b), b)
+        pos += f
+    # and the GPU decodes the whole ragged stream, both kernels
+    for dec in (1, 2):
+        engine.set_decoder(dec)
+        out, blen = engine.decompress_batch(fr)
+        assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
+    engine.set_decoder(0)
+    # GPU decodes the oracle's (reference algorithm's) stream of the same ragged blocks
+    ofr = b"".join(len(c).to_bytes(4, "little") + len(b).to_bytes(4, "little") + c
+                   for b, c in ((b, oracle.compress_block(b, 1)) for b in blocks))
+    out, blen = engine.decompress_batch(ofr)
+    assert out == b"".join(blocks)
+
+
+@pytest.mark.parametrize("n,kind", [(4 << 20, "text"), (4 << 20, "lzsynth"), (16 << 20, "random"), ((16 << 20) + 5, "text")])
+def test_large_blocks(slz4, engine, oracle, n, kind):
+    """BlockMax4MB-sized and larger blocks (u32 hash table path, offsets capped at 65535)."""
+    data = oracle.gen(kind, 1, n, first_block=5).tobytes()
+    fr, flen = engine.compress_batch([data], accel=1)
+    code, out = oracle.decompress_block(fr[8:], n)
+    assert code == n and out == data
+    out2, blen = engine.decompress_batch(fr)
+    assert blen == [n] and out2 == data
+    if n <= (4 << 20):
+        cfg = slz4.BlockConfig(slz4.BlockSize.BlockMax4MB)
+        comp = slz4.compressChunks(cfg, 1, [data], engine)
+        assert slz4.decompressChunksRaw(cfg, comp, engine) == [data]
+        with pytest.raises(slz4.LZ4Error, match="exceeds the maximum block size"):
+            slz4.compressChunks(cfg, 1, [data + b"x"], engine)
+
+
+def test_round_robin_generation_composes(engine):
+    """Block k of the global stream lives on rank k % G: the per-rank generators (first=rank, step=G)
+    interleave to exactly the single-GPU stream (what bench.py relies on for N > 1)."""
+    import torch
+    dev = torch.device("cuda:0")
+    bl, nb, G = 4096, 24, 4
+    whole = torch.empty(nb * bl, dtype=torch.uint8, device=dev)
+    engine.generate("lzsynth", whole, bl, nb)
+    parts = []
+    for r in range(G):
+        p = torch.empty(nb // G * bl, dtype=torch.uint8, device=dev)
+        engine.generate("lzsynth", p, bl, nb // G, first_block=r, block_step=G)
+        parts.append(p.view(nb // G, bl))
+    engine.synchronize()
+    inter = torch.stack(parts, dim=1).reshape(-1)          # local block j of rank g -> global block j*G+g
+    assert torch.equal(inter, whole)
