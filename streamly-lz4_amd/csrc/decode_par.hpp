@@ -292,11 +292,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
             const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
             // prefetch the next window while this batch is copied
+#ifndef PAR_NO_PREFETCH
             {
                 const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
                 wbase = nb;
                 wnext = fetch_window(nb);
             }
+#endif
 
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
             const bool nearSrc = spos >= ringBase;
