@@ -101,6 +101,80 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     uint8_t *op = dst;
     int anchor = 0;
 
+    // Sequence queue: selected sequences are parked one per lane (registers only) and written out
+    // 64 at a time, so the emission code (:1022-1046, :1065-1135) runs with every lane busy instead of
+    // once per window for the handful of lanes that own a match.
+    int qPrev = 0, qStart = 0, qLen = 0, qOff = 0;     // literal start, match start, match length, offset
+    int qCnt = 0;                                      // uniform
+    auto flush_queue = [&]() {
+        if (qCnt == 0) return;
+        const bool act = lane < qCnt;
+        const uint32_t lit = act ? (uint32_t)(qStart - qPrev) : 0u;
+        const uint32_t mc = act ? (uint32_t)(qLen - LZ4_MINMATCH) : 0u;
+        const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
+        const int incl = enc_scan_incl((int)esz);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        uint8_t *o = op + (incl - (int)esz);
+        const uint8_t *litSrc = src + qPrev;
+        // short literal runs: up to four 8-byte chunks per lane, all loads issued before the stores
+        uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        const bool shortRun = act && lit <= 32u;
+        if (shortRun && lit >= 8u) {
+            const uint32_t last = lit - 8u;
+            c0 = *(const u64_unaligned *)(litSrc);
+            if (lit > 8u) c1 = *(const u64_unaligned *)(litSrc + min(8u, last));
+            if (lit > 16u) c2 = *(const u64_unaligned *)(litSrc + min(16u, last));
+            if (lit > 24u) c3 = *(const u64_unaligned *)(litSrc + last);
+        } else if (shortRun && lit > 0u) {
+            for (uint32_t q = 0; q < lit; q++) c0 |= (uint64_t)litSrc[q] << (8u * q);
+        }
+        if (act) {
+            *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
+            if (lit >= 15u) {
+                uint32_t rest = lit - 15u;
+                while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+                *o++ = (uint8_t)rest;
+            }
+        }
+        uint8_t *litDst = o;
+        if (shortRun) {
+            if (lit >= 8u) {
+                const uint32_t last = lit - 8u;
+                *(u64_unaligned *)(litDst) = c0;
+                if (lit > 8u) *(u64_unaligned *)(litDst + min(8u, last)) = c1;
+                if (lit > 16u) *(u64_unaligned *)(litDst + min(16u, last)) = c2;
+                if (lit > 24u) *(u64_unaligned *)(litDst + last) = c3;
+            } else {
+                uint64_t w = c0;
+                uint32_t done = 0;
+                if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
+                for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
+            }
+        }
+        if (act) {
+            o += lit;
+            o[0] = (uint8_t)qOff; o[1] = (uint8_t)((uint32_t)qOff >> 8);
+            o += 2;
+            if (mc >= 15u) {
+                uint32_t rest = mc - 15u;
+                while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+                *o++ = (uint8_t)rest;
+            }
+        }
+        // long literal runs are copied by the whole wave
+        for (uint64_t lm = __ballot(act && lit > 32u); lm; lm &= lm - 1) {
+            const int k = (int)__builtin_ctzll(lm);
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
+            uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
+            const int s0 = __builtin_amdgcn_readlane(qPrev, k);
+            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
+            wave_copy_bytes(d, src + s0, ln);
+        }
+        op += total;
+        qCnt = 0;
+    };
+
     if (n == 0) {                       // cbits/lz4.c:1263-1273: empty input -> single 0 token
         if (lane == 0) dst[0] = 0;
         return 1;
@@ -256,81 +330,21 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     mstart -= back; mcand -= back;
                 }
                 ENC_LAP(4);
-                // ---- sizes, output offsets ----
-                const uint32_t lit = sel ? (uint32_t)(mstart - prevEnd) : 0u;
-                const uint32_t mlen = sel ? (uint32_t)(myEnd - mstart) : 0u;
-                const uint32_t mc = mlen - LZ4_MINMATCH;
-                const uint32_t esz = sel ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
-                const int incl = enc_scan_incl((int)esz);
-                const int total = __builtin_amdgcn_readlane(incl, 63);
-                uint8_t *o = op + (incl - (int)esz);
-                // ---- emit (:1022-1046, :1065-1135): every selected lane writes its own sequence ----
-                if (sel) {
-                    *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
-                    if (lit >= 15u) {
-                        uint32_t rest = lit - 15u;
-                        while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-                        *o++ = (uint8_t)rest;
-                    }
-                }
-                uint8_t *litDst = o;
-                // literals that lie inside this window are taken from the lanes' registers (lane q-p0 holds
-                // bytes [q, q+8)); only a run that starts before the window goes back to memory
-                const bool fromRegs = sel && lit <= 32u && prevEnd >= p0;
+                // ---- park the selected sequences in the queue (stable compaction with one ds_permute
+                // per field: selected lanes go to [qCnt, qCnt+k), the others fill the remaining lanes) ----
                 {
-                    const int lo32 = (int)(uint32_t)v8, hi32 = (int)(uint32_t)(v8 >> 32);
-                    const uint32_t last = (lit >= 8u) ? lit - 8u : 0u;
-                    for (uint32_t q = 0; __ballot(fromRegs && q < max(lit, 1u) && lit > 0u); q += 8u) {
-                        const uint32_t qq = min(q, last);
-                        const int sl = (prevEnd - p0 + (int)qq) & 63;
-                        const uint32_t wl = (uint32_t)par_free_bperm(lo32, sl), wh = (uint32_t)par_free_bperm(hi32, sl);
-                        if (fromRegs && q < lit) {
-                            if (lit >= 8u) {
-                                *(u64_unaligned *)(litDst + qq) = ((uint64_t)wh << 32) | wl;
-                            } else {
-                                uint64_t w = ((uint64_t)wh << 32) | wl;
-                                uint32_t done = 0;
-                                if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
-                                for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
-                            }
-                        }
-                    }
+                    const int k = (int)__builtin_popcountll(selm);
+                    if (qCnt + k > LZ4_WAVE) flush_queue();
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(selm >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)selm, 0u));
+                    const int dest = (sel ? qCnt + rank : qCnt + k + (lane - rank)) & 63;
+                    const int r0 = __builtin_amdgcn_ds_permute(dest << 2, prevEnd);
+                    const int r1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
+                    const int r2 = __builtin_amdgcn_ds_permute(dest << 2, myEnd - mstart);
+                    const int r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
+                    if (lane >= qCnt && lane < qCnt + k) { qPrev = r0; qStart = r1; qLen = r2; qOff = r3; }
+                    qCnt += k;
                 }
-                if (sel) {
-                    if (!fromRegs && lit <= 32u) {              // short run from before the window: its own lane
-                        const uint8_t *litSrc = src + prevEnd;
-                        if (lit >= 8u) {
-                            const uint32_t last = lit - 8u;
-                            for (uint32_t q = 0;; q += 8u) {
-                                const uint32_t qq = min(q, last);
-                                *(u64_unaligned *)(litDst + qq) = *(const u64_unaligned *)(litSrc + qq);
-                                if (q >= last) break;
-                            }
-                        } else {
-                            for (uint32_t q = 0; q < lit; q++) litDst[q] = litSrc[q];
-                        }
-                    }
-                    o += lit;
-                    const uint32_t off = (uint32_t)(mstart - mcand);
-                    o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8);
-                    o += 2;
-                    if (mc >= 15u) {
-                        uint32_t rest = mc - 15u;
-                        while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-                        *o++ = (uint8_t)rest;
-                    }
-                }
-                // long literal runs are copied by the whole wave
-                for (uint64_t lm = __ballot(sel && lit > 32u); lm; lm &= lm - 1) {
-                    const int k = (int)__builtin_ctzll(lm);
-                    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
-                    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
-                    uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
-                    const int s0 = __builtin_amdgcn_readlane(prevEnd, k);
-                    const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
-                    wave_copy_bytes(d, src + s0, ln);
-                }
-                op += total;
                 anchor = lastEnd;
                 p = lastEnd;
                 missAcc = miss0;
@@ -395,20 +409,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     if (run < LZ4_WAVE) break;
                 }
             }
-            // ---- emit sequence (:1022-1046, :1065-1135) ----
-            {
-                const uint32_t lit = (uint32_t)(mpos - anchor);
-                const uint32_t mc = (uint32_t)(ml - LZ4_MINMATCH);
-                const uint32_t off = (uint32_t)(mpos - cpos);
-                uint8_t *tok = op++;
-                if (lane == 0) *tok = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
-                if (lit >= 15) op = emit_ext_len(op, lit - 15);
-                wave_copy_bytes(op, src + anchor, lit);
-                op += lit;
-                if (lane == 0) { op[0] = (uint8_t)off; op[1] = (uint8_t)(off >> 8); }
-                op += 2;
-                if (mc >= 15) op = emit_ext_len(op, mc - 15);
-            }
+            // ---- queue the sequence (written out by flush_queue) ----
+            if (qCnt == LZ4_WAVE) flush_queue();
+            if (lane == qCnt) { qPrev = anchor; qStart = mpos; qLen = ml; qOff = mpos - cpos; }
+            qCnt++;
             anchor = mpos + ml;
             p = anchor;
             missAcc = miss0;
@@ -421,6 +425,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #ifdef ENC_STATS
     if (stats && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stats[i], est[i]);
 #endif
+    flush_queue();
     // ---- last literals (:1204-1231) ----
     {
         const uint32_t lastRun = (uint32_t)(n - anchor);
