@@ -125,6 +125,20 @@ int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, u
                                      int linked, uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
                                      int32_t *result);
 
+/* Many linked streams in one call.  Stream s is the blocks
+ * [streamFirst[s], streamFirst[s+1]) (device array of nStreams + 1 ascending
+ * block indices); inside a stream the semantics are those of linked != 0
+ * above, and no block ever sees another stream's output.  The dependency chain
+ * inside a stream is serial by construction of the format, so a stream is walked
+ * by one wavefront (lane-parallel inside each block) and throughput comes from
+ * the number of streams in the call.
+ * replaces: one decompressChunksRawD state machine per stream,
+ * Internal/LZ4.hs:539-567 -> cbits/lz4.c:2322. */
+int mi355lz4_decompress_streams_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
+                                       const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                                       const int32_t *streamFirst, int nStreams, uint8_t *out,
+                                       const uint64_t *outOff, const int32_t *outCap, int32_t *result);
+
 /* Read the headers of nBlocks framed blocks at blockOff[] and produce
  * outOff[0..nBlocks] = exclusive scan of their uncompressed sizes. */
 int mi355lz4_index_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,

@@ -282,7 +282,7 @@ extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, si
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
-                         uint32_t dict0Len)
+                         uint32_t dict0Len, const int32_t *streamFirst = nullptr, int nStreams = 0)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
     if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || fixedUncomp < 0)
@@ -295,6 +295,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.headerKind = headerKind; a.fixedUncomp = fixedUncomp; a.linked = linked ? 1 : 0;
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
+    a.streamFirst = streamFirst; a.nStreams = nStreams;
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
     else if (c->decoder == 3)
@@ -312,6 +313,19 @@ extern "C" int mi355lz4_decompress_batch_device(mi355lz4_ctx *c, const uint8_t *
 {
     return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, linked, out, outOff,
                          outCap, result, nullptr, 0);
+}
+
+extern "C" int mi355lz4_decompress_streams_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,
+                                                  const uint64_t *blockOff, int nBlocks, int headerKind,
+                                                  int fixedUncomp, const int32_t *streamFirst, int nStreams,
+                                                  uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
+                                                  int32_t *result)
+{
+    if (nStreams < 0 || (nStreams > 0 && !streamFirst))
+        return fail(MI355LZ4_E_ARG, "decompress_streams_device: bad stream table");
+    if (nStreams == 0) return MI355LZ4_OK;
+    return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, 1, out, outOff, outCap,
+                         result, nullptr, 0, streamFirst, nStreams);
 }
 
 extern "C" int mi355lz4_index_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,

@@ -113,9 +113,10 @@ __device__ __forceinline__ int par_scan_incl(int x)
 enum { PS_BATCHES, PS_SEQS, PS_ROUNDS, PS_MATCH_ITERS, PS_LIT_ITERS, PS_HANDOVERS, PS_SLIDES, PS_FULL, PS_FAR,
        PS_T_WINDOW, PS_T_SPEC, PS_T_CHAIN, PS_T_DECODE, PS_T_LIT, PS_T_NEED, PS_T_MATCH, PS_T_FLUSH, PS_T_SEQ, PS_COUNT };
 
-template <bool STATS>
-__device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *bufLo,
-                                const uint8_t *bufHi, ParLds &L, unsigned long long *stats)
+template <bool STATS, bool DICT>
+__device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict,
+                                uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, ParLds &L,
+                                unsigned long long *stats)
 {
     unsigned long long sc[PS_COUNT];
     unsigned long long tmark = 0;
@@ -137,7 +138,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], sc[i]);
         }
     };
-    if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+    if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+    // external dictionary (linked streams, cbits/lz4.c:2347-2355): a match that lies ENTIRELY in the
+    // previous block's output is a far match with another base pointer; one that straddles the seam
+    // (:1883-1911) is left to the sequential decoder
+    if (!DICT) { dict = nullptr; dictLen = 0; }
+    const uint8_t *dictEnd = DICT ? dict + dictLen : dst;
+    const int dictLo = DICT ? -(int)min(dictLen, 65535u) : 0;
 
     const int lane = lane_id();
     const int iend = srcLen;
@@ -280,8 +287,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const int outStart = outEnd - len;
             const int dpos = outStart + (int)lit;            // match destination
             const int spos = dpos - (int)off16;              // match source
-            ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap && spos >= 0 &&
-                 (spos >= ringBase || spos + (int)ml <= flushed);
+            ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap &&
+                 ((spos >= 0 && (spos >= ringBase || spos + (int)ml <= flushed)) ||
+                  (DICT && spos >= dictLo && spos + (int)ml <= 0));
             const uint64_t okm = __ballot(ok);
             const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
             lap(PS_T_DECODE);
@@ -359,7 +367,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const uint64_t farm = __ballot(act && !nearSrc);
             if (farm) {
                 if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
-                const uint8_t *gsrc = dst + spos;
+                const uint8_t *gsrc = (DICT && spos < 0) ? dictEnd + spos : dst + spos;
                 const bool mine = act && !nearSrc;
                 // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
                 // past the match is written.  Far sources never overlap their destination.
@@ -470,9 +478,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         const bool tail = (iend - ip < 64 || cap - op < 128);
         if (STATS && !tail) sc[PS_HANDOVERS]++;
         lap(PS_T_FLUSH);
-        int r = decode_seq_run(st, tail ? 0 : 1, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+        int r = decode_seq_run(st, tail ? 0 : 1, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
         if (r == SEQ_CONTINUE && (!st.fast || iend - st.ip < 64 || cap - st.op < 128))
-            r = decode_seq_run(st, 0, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi);
+            r = decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
         lap(PS_T_SEQ);
         if (r != SEQ_CONTINUE) { publish(); return r; }
         ip = st.ip; op = st.op;

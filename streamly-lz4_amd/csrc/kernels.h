@@ -26,6 +26,8 @@ struct DecodeArgs {
     int32_t *result;
     const uint8_t *dict0;    // linked only: dictionary in force before block 0 (may be null)
     uint32_t dict0Len;
+    const int32_t *streamFirst;   // linked only: stream s = blocks [streamFirst[s], streamFirst[s+1]); null = one stream
+    int nStreams;
 };
 
 struct EncodeArgs {

@@ -57,38 +57,6 @@ __global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
     if (lane_id() == 0) a.result[blk] = r;
 }
 
-// Linked stream (reference semantics of LZ4_decompress_safe_continue with every
-// block in its own allocation, cbits/lz4.c:2347-2355): block i may reference the
-// output of the last block before it that decoded to > 0 bytes.  A block that
-// decodes standalone never consulted a dictionary, so its standalone result IS
-// its linked result; only blocks whose standalone decode failed are re-decoded
-// here, in stream order, with the dictionary in force.  The chain is serial, so
-// one wavefront walks it.  
-__global__ __launch_bounds__(64, 6) void k_decode_fixup_linked(DecodeArgs a)
-{
-    const uint8_t *dict = a.dict0;
-    uint32_t dictLen = a.dict0 ? a.dict0Len : 0;
-    for (int blk = 0; blk < a.nBlocks; blk++) {
-        int r = uni(a.result[blk]);
-        uint8_t *dst = a.out + a.outOff[blk];
-        if (r < 0 && r > -0x7F000000 && dictLen > 0) {   // codec error (not a header rejection)
-            const uint8_t *data = nullptr;
-            int compLen = 0, cap = 0;
-            r = read_block_header(a, blk, data, compLen, cap);
-            if (r == 0)
-                r = decode_block_seq(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen);
-            if (lane_id() == 0) a.result[blk] = r;
-        }
-        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }          // :2331-2333, :2353-2355
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-}
-
-void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
-{
-    if (a.nBlocks > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3(1), dim3(64), 0, s, a);
-}
-
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 {
     if (a.nBlocks <= 0) return;
@@ -322,8 +290,8 @@ __global__ PAR_OCC void k_decode_par(DecodeArgs a, unsigned long long *stats)
     int compLen = 0, cap = 0;
     int r = read_block_header(a, blk, data, compLen, cap);
     if (r == 0)
-        r = decode_block_par<STATS>(data, compLen, a.out + a.outOff[blk], cap, a.framed, a.framed + a.framedLen, lds,
-                                    stats);
+        r = decode_block_par<STATS, false>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
+                                    a.framed + a.framedLen, lds, stats);
     if (lane_id() == 0) a.result[blk] = r;
 }
 
@@ -334,6 +302,53 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
         hipLaunchKernelGGL(k_decode_par<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
     else
         hipLaunchKernelGGL(k_decode_par<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+}
+
+// Linked streams (reference semantics of LZ4_decompress_safe_continue with every
+// block in its own allocation, cbits/lz4.c:2347-2355): block i may reference the
+// output of the last block before it IN ITS STREAM that decoded to > 0 bytes.  A
+// block that decodes standalone never consulted a dictionary, so its standalone
+// result IS its linked result; only blocks whose standalone decode failed are
+// re-decoded here, in stream order, with the dictionary in force.  The chain
+// inside one stream is serial (block i needs the bytes of block i-1), so one
+// wavefront walks each stream with the lane-parallel decoder; independent
+// streams run side by side.  
+__global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int sIdx = (int)blockIdx.x;
+    int b0 = 0, b1 = a.nBlocks;
+    const uint8_t *dict = nullptr;
+    uint32_t dictLen = 0;
+    if (a.streamFirst) {
+        b0 = min(max(uni(a.streamFirst[sIdx]), 0), a.nBlocks);
+        b1 = min(max(uni(a.streamFirst[sIdx + 1]), b0), a.nBlocks);
+    } else if (a.dict0) {
+        dict = a.dict0; dictLen = a.dict0Len;
+    }
+    for (int blk = b0; blk < b1; blk++) {
+        int r = uni(a.result[blk]);
+        uint8_t *dst = a.out + a.outOff[blk];
+        if (r < 0 && r > -0x7F000000 && dictLen > 0) {   // codec error (not a header rejection)
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, blk, data, compLen, cap);
+            if (r == 0)
+                r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed,
+                                            a.framed + a.framedLen, lds, nullptr);
+            r = uni(r);
+            if (lane_id() == 0) a.result[blk] = r;
+        }
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }          // :2331-2333, :2353-2355
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    }
+}
+
+void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    const int ns = a.streamFirst ? a.nStreams : 1;
+    if (ns > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)ns), dim3(64), 0, s, a);
 }
 
 // Two-wave lane-parallel decoder (decode_par2.hpp): one 128-thread workgroup per block,

@@ -83,6 +83,8 @@ def _load():
     sig("mi355lz4_compact_device", C.c_int, vp, vp, C.c_size_t, vp, C.c_int, vp, C.c_size_t, vp)
     sig("mi355lz4_decompress_batch_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, C.c_int,
         vp, vp, vp, vp)
+    sig("mi355lz4_decompress_streams_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp,
+        C.c_int, vp, vp, vp, vp)
     sig("mi355lz4_index_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp)
     sig("mi355lz4_compress_batch", C.c_int, vp, C.POINTER(_u8p), _i32p, C.c_int, C.c_int, C.c_int, _u8p,
         C.c_size_t, C.POINTER(C.c_size_t), _i32p, _i32p)
@@ -131,7 +133,7 @@ DECLARED_SYMBOLS = [
     "mi355lz4_version", "mi355lz4_last_error", "mi355lz4_device_count", "mi355lz4_create", "mi355lz4_destroy",
     "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
-    "mi355lz4_decompress_batch_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
+    "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
     "mi355lz4_decompress_batch", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
     "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
     "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
@@ -292,6 +294,14 @@ class Engine:
             self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
             int(fixed_uncomp), int(bool(linked)), _dptr(out), _dptr(out_off), _dptr(out_cap), _dptr(result)),
             "decompress_batch_device")
+
+    def decompress_streams_device(self, framed, framed_len, block_off, n_blocks, stream_first, n_streams, out,
+                                  out_off, result, header_kind=8, fixed_uncomp=0, out_cap=None):
+        """Linked streams: stream s = blocks [stream_first[s], stream_first[s+1]) (int32 device tensor)."""
+        _check(lib.mi355lz4_decompress_streams_device(
+            self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
+            int(fixed_uncomp), _dptr(stream_first), int(n_streams), _dptr(out), _dptr(out_off), _dptr(out_cap),
+            _dptr(result)), "decompress_streams_device")
 
     def index_device(self, framed, framed_len, block_off, n_blocks, out_off, header_kind=8, fixed_uncomp=0):
         _check(lib.mi355lz4_index_device(self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks),

@@ -1,0 +1,60 @@
+"""Linked-stream decode at a size where the rate means something: streams written by the
+reference's own linked compressor (oracle on the host), decoded by the GPU in one call, checked
+bit-exact, and the rate written to gpurun_out/linked_rate.json.  The oracle is only the data source
+and the checker here; the timed region is the GPU call."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from test_parity_gpu import _stream_layout
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n_streams,blocks_per_stream", [(2048, 2), (512, 8), (8, 64)])
+def test_linked_stream_rate(engine, slz4, oracle, n_streams, blocks_per_stream):
+    import torch
+    dev = torch.device("cuda:0")
+    bl = 65536
+    # a handful of distinct streams, repeated: host compression stays at a few seconds
+    distinct = min(n_streams, 16)
+    datas = [oracle.gen("text", blocks_per_stream, bl, first_block=1000 * s).tobytes() for s in range(distinct)]
+    frs_d = [oracle.frame_compress(d, bl, 1, 8, True) for d in datas]
+    frs = [frs_d[s % distinct] for s in range(n_streams)]
+    blob, boff, first, ulen = _stream_layout(frs)
+    nb = len(boff)
+    buf = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    off = torch.tensor(boff, dtype=torch.int64, device=dev)
+    ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
+    out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
+    res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    sf = torch.tensor(first, dtype=torch.int32, device=dev)
+    e0, e1 = slz4.Event(), slz4.Event()
+    best = 1e9
+    for _ in range(3):
+        engine.record(e0)
+        engine.decompress_streams_device(buf, len(blob), off, nb, sf, n_streams, out, ooff, res)
+        engine.record(e1)
+        engine.synchronize()
+        best = min(best, engine.elapsed_ms(e0, e1))
+    assert bool((res == bl).all().item())
+    ref = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    per = blocks_per_stream * bl
+    for s in range(0, n_streams, max(1, n_streams // 64)):
+        d = s % distinct
+        assert torch.equal(out[s * per:(s + 1) * per], ref[d * per:(d + 1) * per]), s
+    # how many blocks really needed their predecessor
+    engine.decompress_batch_device(buf, len(blob), off, nb, out, ooff, res, linked=False)
+    engine.synchronize()
+    dependent = int((res < 0).sum().item())
+    rate = nb * bl / best / 1e6
+    rec = {"streams": n_streams, "blocks_per_stream": blocks_per_stream, "block_len": bl, "data": "text, reference-linked",
+           "dependent_blocks": dependent, "blocks": nb, "ms": round(best, 3), "GBps_uncompressed": round(rate, 2)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)

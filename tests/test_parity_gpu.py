@@ -442,3 +442,108 @@ def test_round_robin_generation_composes(engine):
     engine.synchronize()
     inter = torch.stack(parts, dim=1).reshape(-1)          # local block j of rank g -> global block j*G+g
     assert torch.equal(inter, whole)
+
+
+# --------------------------------------------------------------------------------------------
+# many linked streams in one call: each stream is the reference compressor's
+# own output (blocks linked to their predecessor), streams are independent of each other
+# --------------------------------------------------------------------------------------------
+def _stream_layout(frs, meta=8):
+    """frs: framed bytes per stream -> (concatenated bytes, blockOff, streamFirst, uncompressed lengths)."""
+    blob, boff, first, ulen = b"", [], [0], []
+    for fr in frs:
+        pos = 0
+        while pos < len(fr):
+            c = int.from_bytes(fr[pos:pos + 4], "little")
+            boff.append(len(blob) + pos)
+            ulen.append(int.from_bytes(fr[pos + 4:pos + 8], "little"))
+            pos += meta + c
+        blob += fr
+        first.append(len(boff))
+    return blob, boff, first, ulen
+
+
+def _decode_streams(engine, frs, linked_mode):
+    import torch
+    dev = torch.device("cuda:0")
+    blob, boff, first, ulen = _stream_layout(frs)
+    nb = len(boff)
+    buf = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    off = torch.tensor(boff, dtype=torch.int64, device=dev)
+    ooff_h = np.concatenate([[0], np.cumsum(ulen)]).astype(np.int64)
+    ooff = torch.from_numpy(ooff_h).to(dev)
+    out = torch.zeros(int(ooff_h[-1]) + 64, dtype=torch.uint8, device=dev)
+    res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    if linked_mode == "streams":
+        sf = torch.tensor(first, dtype=torch.int32, device=dev)
+        engine.decompress_streams_device(buf, len(blob), off, nb, sf, len(frs), out, ooff, res)
+    else:
+        engine.decompress_batch_device(buf, len(blob), off, nb, out, ooff, res, linked=(linked_mode == "one"))
+    engine.synchronize()
+    return out[: int(ooff_h[-1])].cpu().numpy().tobytes(), res.cpu().tolist(), ulen, first
+
+
+@pytest.mark.parametrize("decoder", [1, 2])
+def test_linked_streams_many(engine, oracle, decoder):
+    engine.set_decoder(decoder)
+    try:
+        rng = random.Random(7)
+        datas, frs = [], []
+        for s in range(24):
+            bl = rng.choice([4096, 20000, 65536])
+            nb = rng.randint(1, 6)
+            kind = "text" if s % 3 else "lzsynth"
+            d = oracle.gen(kind, nb, bl, first_block=100 * s).tobytes()
+            if s % 4 == 1:                                   # periodic: matches that straddle the seam (:1883-1911)
+                pat = d[:3001]
+                d = (pat * (len(d) // len(pat) + 1))[: len(d)]
+            datas.append(d)
+            frs.append(oracle.frame_compress(d, bl, 1, 8, True))
+        out, res, ulen, first = _decode_streams(engine, frs, "streams")
+        assert res == ulen
+        assert out == b"".join(datas)
+        # the streams really are linked: decoded block by block they fail with the reference's codes ...
+        out0, res0, _, _ = _decode_streams(engine, frs, "none")
+        failing = [i for i, r in enumerate(res0) if r < 0]
+        assert len(failing) > 10
+        blocks = split_blocks(b"".join(frs))
+        for i in failing[:20]:
+            code, _ = oracle.decompress_block(blocks[i][8:], ulen[i])
+            assert code == res0[i]
+        # ... and treated as ONE stream, the first block of stream s > 0 that reaches back sees the wrong
+        # predecessor, so the per-stream table is what keeps streams apart
+        heads = set(first[:-1])
+        assert all(i not in heads for i in failing)          # a stream's first block never needs a dictionary
+    finally:
+        engine.set_decoder(0)
+
+
+def test_linked_streams_error_is_local(engine, oracle):
+    """A corrupt block poisons only the rest of its own stream, with the reference's codes."""
+    frs, datas = [], []
+    for s in range(6):
+        d = oracle.gen("text", 4, 16384, first_block=10 * s).tobytes()
+        datas.append(d)
+        frs.append(oracle.frame_compress(d, 16384, 1, 8, True))
+    bad = bytearray(frs[2])
+    blk = split_blocks(frs[2])
+    pos = len(blk[0]) + 8                                    # first token of block 1 of stream 2
+    bad[pos] = 0x1F                                          # 1 literal, then an offset that is almost surely wrong
+    bad[pos + 2], bad[pos + 3] = 0xFF, 0xFF
+    frs2 = list(frs)
+    frs2[2] = bytes(bad)
+    out, res, ulen, first = _decode_streams(engine, frs2, "streams")
+    for s in range(6):
+        lo, hi = first[s], first[s + 1]
+        if s != 2:
+            assert res[lo:hi] == ulen[lo:hi]
+            o = sum(ulen[:lo])
+            assert out[o:o + len(datas[s])] == datas[s]
+    # reference behaviour for stream 2, block by block with the previous GOOD output as dictionary
+    lo = first[2]
+    dict_bytes = None
+    for j, b in enumerate(split_blocks(frs2[2])):
+        code, dec = oracle.decompress_block(b[8:], ulen[lo + j], dict_bytes)
+        assert res[lo + j] == code, (j, res[lo + j], code)
+        if code > 0:
+            dict_bytes = dec
