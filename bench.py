@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default: workload's)")
     ap.add_argument("--decoder", type=int, default=0, help="0 auto, 1 sequence-at-a-time, 2 lane-parallel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the multi-threaded best-case CPU figure")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0)
     ap.add_argument("--gather", action="store_true", help="also time the RCCL ordered gather of the framed output (N>1)")
     args = ap.parse_args()
@@ -194,9 +195,19 @@ def main():
             traffic = json.load(open(tpath)).get("%s:%s" % (args.workload, dom))
         except Exception:
             traffic = None
+    # what a plain device-to-device copy of the same U bytes reaches on this box (read + write)
+    copy_GBps = None
+    try:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        out.copy_(src); torch.cuda.synchronize()
+        ev0.record(); out.copy_(src); ev1.record(); torch.cuda.synchronize()
+        copy_GBps = round(2 * U / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+    except Exception:
+        copy_GBps = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": U + Cbytes, "avg_launch_ms": round(avg_ms, 4)}
+                "algorithmic_bytes_per_launch": U + Cbytes, "avg_launch_ms": round(avg_ms, 4),
+                "device_copy_GBps": copy_GBps}
 
     # ---- CPU baseline on a bounded sample of the same input (rank 0, N=1 only) ----
     cpu = None
@@ -214,6 +225,13 @@ def main():
                          % (ns, ns * BL >> 20, kind),
                "decompress_GBps": round(cpu_dec, 3), "compress_GBps": round(cpu_cmp, 3),
                "ratio": round(r["raw_bytes"] / (r["comp_bytes"] + 8 * ns), 4)}
+        if not args.no_cpu_all_cores:
+            # best-case CPU, NOT reference behaviour (its API is one serial stream): one independent
+            # linked context per host thread over contiguous block ranges of the same sample
+            ra = orc.cpu_baseline_all_cores(blocks, accel=accel)
+            cpu["all_cores"] = {"cores": ra["threads"], "decompress_GBps": round(ra["raw_bytes"] / ra["decomp_s"] / 1e9, 3),
+                                "compress_GBps": round(ra["raw_bytes"] / ra["comp_s"] / 1e9, 3),
+                                "note": "best-case CPU, not reference behaviour: one stream per thread"}
 
     line = {
         "metric": "GB/s uncompressed (compress+decompress), 64 KiB blocks, 1/2/4/8 GPU",

@@ -118,16 +118,16 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                                 uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, ParLds &L,
                                 unsigned long long *stats)
 {
-    unsigned long long sc[PS_COUNT];
-    unsigned long long tmark = 0;
+    uint32_t sc[PS_COUNT];                 // wave-uniform (kept in scalar registers)
+    uint32_t tmark = 0;
     if (STATS) {
 #pragma unroll
         for (int i = 0; i < PS_COUNT; i++) sc[i] = 0;
-        tmark = __builtin_amdgcn_s_memtime();
+        tmark = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());
     }
     auto lap = [&](int which) {
         if (STATS) {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            const uint32_t now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());
             sc[which] += now - tmark;
             tmark = now;
         }
@@ -135,7 +135,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     auto publish = [&]() {
         if (STATS && lane_id() == 0) {
 #pragma unroll
-            for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], sc[i]);
+            for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], (unsigned long long)sc[i]);
         }
     };
     if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
@@ -157,10 +157,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     // 16 bytes of the compressed stream for this lane's slot of the window that starts at `base`
     auto fetch_window = [&](uintptr_t base) -> uint4 {
         const uint8_t *q = (const uint8_t *)(base + 16u * (uint32_t)lane);
-        if (q >= bufLo && q + 16 <= bufHi) return *(const uint4 *)q;
+        if (q >= bufLo && q + 16 <= bufHi) {
+            const par_v4 v = *as_global((const par_v4 *)q);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
         uint32_t w[4] = {0, 0, 0, 0};
         for (int k = 0; k < 16; k++)
-            if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)q[k] << (8 * (k & 3));
+            if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)as_global(q)[k] << (8 * (k & 3));
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
 
@@ -196,6 +199,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
     uintptr_t wbase = (uintptr_t)src & ~(uintptr_t)15;     // window base whose data is in `wnext`
     uint4 wnext = fetch_window(wbase);
+    bool winStale = true;                                  // L.win does not hold the window at wbase yet
     const uint8_t *jumpB = (const uint8_t *)L.jump;
     if (lane == 0) L.jump[PAR_NODES] = PAR_END;            // absorbing state
 
@@ -211,9 +215,14 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const int ipW0 = ip - wofs;                    // block-relative position of window byte 0
             const int iendW = iend - ipW0;                 // block end in window coordinates
             const int inLim = min(iendW - 32, PAR_WIN);    // a plain sequence must end at or before this
-            if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); }   // no prefetch after a handover
-            *(uint4 *)&L.win[16 * lane] = wnext;
-            wave_fence();
+            // L.win already holds this window (stored at the end of the previous batch) unless this is
+            // the first batch or the one after a handover
+            if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); winStale = true; }
+            if (winStale) {
+                *(uint4 *)&L.win[16 * lane] = wnext;
+                winStale = false;
+                wave_fence();
+            }
             lap(PS_T_WINDOW);
 
             // ---------------- 2. speculative parse (registers only) ----------------
@@ -299,14 +308,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool act = lane < nseq;
             const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
             const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
-            // prefetch the next window while this batch is copied
-#ifndef PAR_NO_PREFETCH
+            // prefetch the next window while this batch is copied (measured: issuing it here, before the
+            // far pass, beats issuing it after, although the far pass then also waits for it)
             {
                 const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
                 wbase = nb;
                 wnext = fetch_window(nb);
             }
-#endif
 
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
             const bool nearSrc = spos >= ringBase;
@@ -374,23 +382,35 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const uint32_t step = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
                 const uint32_t last = ml - step;
                 for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
-                    if (mine && base < ml) {
+                    // every load of the pass is issued before the first store waits for one: a single
+                    // round trip to L2/HBM per 32 bytes, whatever mix of chunk sizes the lanes have
+                    par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+                    const bool on = mine && base < ml;
+                    const uint32_t o0 = (step == 16) ? min(base, last) : 0u;
+                    const uint32_t o1 = (step == 16) ? min(base + 16u, last) : last;
+                    if (on) {
                         if (step == 16) {
-                            const uint32_t o0 = min(base, last), o1 = min(base + 16u, last);
-                            par_v4 v0, v1;
                             __builtin_memcpy(&v0, gsrc + o0, 16);
                             __builtin_memcpy(&v1, gsrc + o1, 16);
+                        } else if (step == 8) {
+                            const uint64_t a = *(const par_u64u *)(gsrc), b = *(const par_u64u *)(gsrc + last);
+                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
+                            v1.x = (uint32_t)b; v1.y = (uint32_t)(b >> 32);
+                        } else {
+                            v0.x = *(const par_u32u *)(gsrc);
+                            v1.x = *(const par_u32u *)(gsrc + last);
+                        }
+                    }
+                    if (on) {
+                        if (step == 16) {
                             *(par_v4u *)&L.ring[mdA + o0] = v0;
                             *(par_v4u *)&L.ring[mdA + o1] = v1;
                         } else if (step == 8) {
-                            const uint64_t v0 = *(const par_u64u *)(gsrc), v1 = *(const par_u64u *)(gsrc + last);
-                            *(par_u64u *)&L.ring[mdA] = v0;
-                            *(par_u64u *)&L.ring[mdA + last] = v1;
+                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
+                            *(par_u64u *)&L.ring[mdA + last] = ((uint64_t)v1.y << 32) | v1.x;
                         } else {
-                            const uint32_t v0 = *(const par_u32u *)(gsrc);
-                            const uint32_t v1 = *(const par_u32u *)(gsrc + last);
-                            *(par_u32u *)&L.ring[mdA] = v0;
-                            *(par_u32u *)&L.ring[mdA + last] = v1;
+                            *(par_u32u *)&L.ring[mdA] = v0.x;
+                            *(par_u32u *)&L.ring[mdA + last] = v1.x;
                         }
                     }
                 }
@@ -454,6 +474,11 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // ---------------- advance, 8. flush, slide ----------------
             op = opNext;
             ip = ipNext;
+            // the next window goes to LDS now (nobody reads the old one any more): this is where the wave
+            // waits for the prefetch, BEFORE the flush issues its stores, so that no later wait for a load
+            // also has to wait for those stores to be acknowledged
+            *(uint4 *)&L.win[16 * lane] = wnext;
+            wave_fence();
             flush(op, false);
             if (op - ringBase + (int)A + PAR_BATCH_OUT + 32 > PAR_RING) {
                 if (STATS) sc[PS_SLIDES]++;

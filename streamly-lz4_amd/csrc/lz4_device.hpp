@@ -34,6 +34,16 @@ __device__ __forceinline__ int64_t uni64(int64_t v)
 // pipeline already executes in order, so no s_waitcnt is needed.
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+// Pointers rebuilt from integers (or passed through a non-inlined call) are "flat" to the compiler:
+// flat loads wait for EVERY outstanding vector-memory operation before they issue and again before
+// their data is used.  These casts assert what is true of every buffer the engine touches: it is
+// device global memory.
+#define LZ4_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const LZ4_GLOBAL T *as_global(const T *p) { return (const LZ4_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ LZ4_GLOBAL T *as_global(T *p) { return (LZ4_GLOBAL T *)p; }
+
 __device__ __forceinline__ int32_t load_le32(const uint8_t *p)
 {
     return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
