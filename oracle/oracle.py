@@ -164,60 +164,109 @@ def have_reference():
     return os.path.exists(os.path.join(_HERE, "_ref", "liblz4ref.so")) or os.path.exists("/root/reference/cbits/lz4.c")
 
 
-def cpu_baseline_all_cores(blocks, accel=1, threads=None):
+def cpu_share():
+    """Host threads this process may really use: the cgroup CPU quota when one is set, else the CPU
+    count capped at 16 (a 1-GPU box's share of its host)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+class _CpuJob:
+    """Buffers + timed calls for one host thread's share of the CPU baseline."""
+
+    def __init__(self, blocks, accel):
+        if have_reference():
+            self.lib, self.prefix, self.kind = Reference().lib, "ref", "reference"
+        else:
+            self.lib, self.prefix, self.kind = Oracle().lib, "orc", "port"
+        self.accel = accel
+        n = self.n = len(blocks)
+        self.ins = [np.frombuffer(b, dtype=np.uint8).copy() for b in blocks]
+        self.lens = np.array([a.size for a in self.ins], dtype=np.int32)
+        bounds = [int(a.size + a.size // 255 + 16) for a in self.ins]
+        self.comps = [np.zeros(b + _PAD, dtype=np.uint8) for b in bounds]
+        self.outs = [np.zeros(a.size + _PAD, dtype=np.uint8) for a in self.ins]
+        self.clens = np.zeros(n, dtype=np.int32)
+        self.res = np.zeros(n, dtype=np.int32)
+        PP = _u8p * n
+        self.in_pp = PP(*[_ptr(a) for a in self.ins])
+        self.comp_pp = PP(*[_ptr(a) for a in self.comps])
+        self.out_pp = PP(*[_ptr(a) for a in self.outs])
+
+    def compress(self):
+        ip = C.POINTER(C.c_int)
+        return getattr(self.lib, self.prefix + "_time_compress")(
+            self.in_pp, self.lens.ctypes.data_as(ip), self.n, self.accel, self.comp_pp, self.clens.ctypes.data_as(ip))
+
+    def decompress(self):
+        ip = C.POINTER(C.c_int)
+        return getattr(self.lib, self.prefix + "_time_decompress")(
+            self.comp_pp, self.clens.ctypes.data_as(ip), self.n, self.out_pp, self.lens.ctypes.data_as(ip),
+            self.res.ctypes.data_as(ip))
+
+    def verify(self):
+        for a, o, r in zip(self.ins, self.outs, self.res):
+            if r != a.size or not np.array_equal(o[: a.size], a):
+                raise RuntimeError("cpu baseline round trip mismatch")
+
+
+def cpu_baseline_all_cores(blocks, accel=1, threads=None, reps=2):
     """Best-case CPU (NOT the reference's behaviour, whose API is serial): `threads` host threads, one
-    independent linked context per thread over a contiguous range of `blocks`.  Wall time covers all
-    threads.  Used only by bench.py's cpu_baseline leg."""
+    independent linked context per thread over a contiguous range of `blocks`.  All threads start each
+    timed phase together (barrier); the phase time is the wall time from the barrier to the last
+    thread's return.  Used only by bench.py's cpu_baseline leg."""
+    import threading
     import time
-    from concurrent.futures import ThreadPoolExecutor
-    threads = threads or (os.cpu_count() or 1)
+    threads = threads or cpu_share()
     threads = max(1, min(threads, len(blocks)))
     per = (len(blocks) + threads - 1) // threads
     parts = [blocks[i:i + per] for i in range(0, len(blocks), per)]
+    jobs = [_CpuJob(p, accel) for p in parts]
+    nt = len(jobs)
 
-    def work(part):
-        return cpu_baseline(part, accel, reps=2)
+    def phase(fn_name):
+        bar = threading.Barrier(nt + 1)
+        ends = [0.0] * nt
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(len(parts)) as ex:
-        rs = list(ex.map(work, parts))
-    wall = time.perf_counter() - t0
-    # the slowest thread bounds each phase; compression and decompression ran back to back in each thread
-    comp_s = max(r["comp_s"] for r in rs)
-    decomp_s = max(r["decomp_s"] for r in rs)
-    return {"kind": rs[0]["kind"], "threads": len(parts), "comp_s": comp_s, "decomp_s": decomp_s, "wall_s": wall,
-            "raw_bytes": sum(r["raw_bytes"] for r in rs), "comp_bytes": sum(r["comp_bytes"] for r in rs)}
+        def run(i):
+            fn = getattr(jobs[i], fn_name)
+            bar.wait()
+            fn()
+            ends[i] = time.perf_counter()
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(nt)]
+        for t in ts:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in ts:
+            t.join()
+        return max(ends) - t0
+
+    comp_s = min(phase("compress") for _ in range(reps))
+    decomp_s = min(phase("decompress") for _ in range(reps))
+    for j in jobs:
+        j.verify()
+    return {"kind": jobs[0].kind, "threads": nt, "comp_s": comp_s, "decomp_s": decomp_s,
+            "raw_bytes": int(sum(int(j.lens.sum()) for j in jobs)), "comp_bytes": int(sum(int(j.clens.sum()) for j in jobs))}
 
 
 def cpu_baseline(blocks, accel=1, reps=3):
     """Time compress+decompress of `blocks` (list of bytes) with the reference call
     sequence on ONE host thread.  Returns dict(kind, comp_s, decomp_s, comp_bytes).
     Used only by bench.py's cpu_baseline leg."""
-    if have_reference():
-        lib, prefix, kind = Reference().lib, "ref", "reference"
-    else:
-        lib, prefix, kind = Oracle().lib, "orc", "port"
-    n = len(blocks)
-    ins = [np.frombuffer(b, dtype=np.uint8).copy() for b in blocks]
-    lens = np.array([a.size for a in ins], dtype=np.int32)
-    bounds = [int(a.size + a.size // 255 + 16) for a in ins]
-    comps = [np.zeros(b + _PAD, dtype=np.uint8) for b in bounds]
-    outs = [np.zeros(a.size + _PAD, dtype=np.uint8) for a in ins]
-    clens = np.zeros(n, dtype=np.int32)
-    res = np.zeros(n, dtype=np.int32)
-    PP = _u8p * n
-    in_pp = PP(*[_ptr(a) for a in ins])
-    comp_pp = PP(*[_ptr(a) for a in comps])
-    out_pp = PP(*[_ptr(a) for a in outs])
-    ip = C.POINTER(C.c_int)
-    best_c = best_d = 1e30
-    for _ in range(reps):
-        t = getattr(lib, prefix + "_time_compress")(in_pp, lens.ctypes.data_as(ip), n, accel, comp_pp, clens.ctypes.data_as(ip))
-        best_c = min(best_c, t)
-    for _ in range(reps):
-        t = getattr(lib, prefix + "_time_decompress")(comp_pp, clens.ctypes.data_as(ip), n, out_pp, lens.ctypes.data_as(ip), res.ctypes.data_as(ip))
-        best_d = min(best_d, t)
-    for a, o, r in zip(ins, outs, res):
-        if r != a.size or not np.array_equal(o[: a.size], a):
-            raise RuntimeError("cpu baseline round trip mismatch")
-    return {"kind": kind, "comp_s": best_c, "decomp_s": best_d, "comp_bytes": int(clens.sum()), "raw_bytes": int(lens.sum())}
+    job = _CpuJob(blocks, accel)
+    best_c = min(job.compress() for _ in range(reps))
+    best_d = min(job.decompress() for _ in range(reps))
+    job.verify()
+    return {"kind": job.kind, "comp_s": best_c, "decomp_s": best_d, "comp_bytes": int(job.clens.sum()),
+            "raw_bytes": int(job.lens.sum())}

@@ -21,7 +21,7 @@ KERNEL_OF = {"decompress": "k_decode_par<false>", "compress": "k_encode<"}
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None     # gpurun merges runs: take the newest
 
 
 def pmc_avg(path, kernel_sub, counter):
