@@ -13,8 +13,10 @@
 //   2. speculate  every lane parses 8 candidate token positions (512 candidates)
 //                 from registers: where would the next token be if one started here?
 //   3. chain      pointer jumping over that successor table: after round k lanes
-//                 0..2^k-1 hold the first 2^k real token positions, so 6 rounds put
-//                 sequence r on lane r -- the serial chain is resolved in log time.
+//                 0..2^k-1 hold the first 2^k real token positions.  Three rounds give
+//                 jump^8 for every node and lanes 0..7; then lanes 8g..8g+7 follow the
+//                 real chain from lanes 8(g-1)..8g-1 (one 8-lane gather per group), so
+//                 sequence r ends up on lane r.
 //   4. decode     lane r decodes sequence r (lengths, offset); a DPP wave scan of the
 //                 output lengths gives every sequence its output position.
 //   5. far        matches whose source was already flushed to global memory are
@@ -22,7 +24,8 @@
 //   6. literals   lane-per-sequence copy, LDS window -> LDS output ring.
 //   7. matches    dependency rounds: a match is ready when every sequence its
 //                 source overlaps is complete (64-bit ballot mask); ready lanes copy
-//                 8 bytes per step in lock step inside the LDS ring.
+//                 two chunks (2 x 16 / 8 / 4 bytes) per step inside the LDS ring, all
+//                 reads of a step before its first write.
 //   8. flush      completed output leaves the ring with aligned 16-byte stores.
 //
 // Only "plain interior" sequences are handled here: single-byte length
@@ -251,27 +254,31 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
             // ---------------- 3. chain: sequence r -> lane r ----------------
             uint32_t c2 = (lane == 0) ? 2u * (uint32_t)wofs : (uint32_t)PAR_END;   // 2 x token position
+            // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
+            // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
+            // one 8-lane gather per group instead of two more squarings of all 512 nodes.
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < 3; k++) {
                 const int d = 1 << k;
                 const int cj = (int)*(const uint16_t *)(jumpB + c2);
-                if (k < 5) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) J[j] = (uint32_t)*(const uint16_t *)(jumpB + J[j]);
-                }
+                for (int j = 0; j < 8; j++) J[j] = (uint32_t)*(const uint16_t *)(jumpB + J[j]);
                 int sh;
                 if (k == 0) sh = par_row_shr<1>(cj);
                 else if (k == 1) sh = par_row_shr<2>(cj);
-                else if (k == 2) sh = par_row_shr<4>(cj);
-                else if (k == 3) sh = par_row_shr<8>(cj);
-                else sh = par_bperm(cj, (lane - d) & 63);
+                else sh = par_row_shr<4>(cj);
                 if (lane >= d && lane < 2 * d) c2 = (uint32_t)sh;
-                if (k < 5) {
-                    wave_fence();
-                    *(uint4 *)&L.jump[8 * lane] =
-                        make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
-                    wave_fence();
-                }
+                wave_fence();
+                *(uint4 *)&L.jump[8 * lane] =
+                    make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
+                wave_fence();
+            }
+#pragma unroll
+            for (int g = 1; g < 8; g++) {
+                int cj = PAR_END;
+                if (lane >= 8 * (g - 1) && lane < 8 * g) cj = (int)*(const uint16_t *)(jumpB + c2);
+                const int sh = (g & 1) ? par_row_shr<8>(cj) : par_bperm(cj, (lane - 8) & 63);
+                if (lane >= 8 * g && lane < 8 * g + 8) c2 = (uint32_t)sh;
             }
             lap(PS_T_CHAIN);
 
@@ -323,6 +330,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups never read their own writes
             const bool g16 = grp && ml >= 16;                       // ... as two 16-byte chunks
             const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
+            const bool g4 = ml < 8 && off16 >= ml;                  // 4 <= ml < 8, no self-overlap: two 4-byte chunks
+            const bool fastc = g16 || g8 || g4;
 
             // ---------------- dependency masks (independent of the copies below: issued first so that
             // their cross-lane traffic overlaps the literal and far copies) ----------------
@@ -422,38 +431,53 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
             bool pending = act && nearSrc;                              // my match still has to be copied
             const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
-            const uint32_t last8 = ml - 8;
             while (~done) {
                 const bool mine = pending && ((need & ~done) == 0ull);
                 if (STATS) sc[PS_ROUNDS]++;
-                // lanes whose 32-byte groups never read their own writes: 2 x 16 bytes per step
-                for (uint32_t base = 0; __ballot(mine && g16 && base < ml); base += 32) {
+                // lanes whose chunks never read their own writes: two chunks per step (2 x 16, 2 x 8 or 2 x 4
+                // bytes by class), every lane's reads issued before the first write, so that a round costs
+                // one LDS round trip per 32 bytes whatever mix of classes is ready
+                for (uint32_t base = 0; __ballot(mine && fastc && base < ml); base += 32) {
                     if (STATS) sc[PS_MATCH_ITERS]++;
-                    if (mine && g16 && base < ml) {
-                        const uint32_t last16 = ml - 16;
-                        const uint32_t o0 = min(base, last16), o1 = min(base + 16u, last16);
-                        const par_v4 v0 = *(const par_v4u *)&L.ring[msA + o0];
-                        const par_v4 v1 = *(const par_v4u *)&L.ring[msA + o1];
-                        *(par_v4u *)&L.ring[mdA + o0] = v0;
-                        *(par_v4u *)&L.ring[mdA + o1] = v1;
+                    const bool on = mine && fastc && base < ml;
+                    const uint32_t cs = g16 ? 16u : (g8 ? 8u : 4u);
+                    const uint32_t lastc = ml - cs;
+                    const uint32_t o0 = g16 ? min(base, lastc) : 0u;
+                    const uint32_t o1 = g16 ? min(base + 16u, lastc) : lastc;
+                    par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+                    if (on) {
+                        if (g16) {
+                            v0 = *(const par_v4u *)&L.ring[msA + o0];
+                            v1 = *(const par_v4u *)&L.ring[msA + o1];
+                        } else if (g8) {
+                            const uint64_t a = *(const par_u64u *)&L.ring[msA], c = *(const par_u64u *)&L.ring[msA + o1];
+                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
+                            v1.x = (uint32_t)c; v1.y = (uint32_t)(c >> 32);
+                        } else {
+                            v0.x = *(const par_u32u *)&L.ring[msA];
+                            v1.x = *(const par_u32u *)&L.ring[msA + o1];
+                        }
                     }
-                    wave_fence();
-                }
-                if (__ballot(mine && g8)) {                                 // 8 <= ml < 16: two 8-byte chunks
-                    if (STATS) sc[PS_MATCH_ITERS]++;
-                    if (mine && g8) {
-                        const uint64_t v0 = *(const par_u64u *)&L.ring[msA], v1 = *(const par_u64u *)&L.ring[msA + last8];
-                        *(par_u64u *)&L.ring[mdA] = v0;
-                        *(par_u64u *)&L.ring[mdA + last8] = v1;
+                    if (on) {
+                        if (g16) {
+                            *(par_v4u *)&L.ring[mdA + o0] = v0;
+                            *(par_v4u *)&L.ring[mdA + o1] = v1;
+                        } else if (g8) {
+                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
+                            *(par_u64u *)&L.ring[mdA + o1] = ((uint64_t)v1.y << 32) | v1.x;
+                        } else {
+                            *(par_u32u *)&L.ring[mdA] = v0.x;
+                            *(par_u32u *)&L.ring[mdA + o1] = v1.x;
+                        }
                     }
                     wave_fence();
                 }
                 // short offsets (rare): steps of 8 / 4 / 1 bytes one after the other, because a step may
                 // read the previous step's bytes; last chunk re-anchored at the end (idempotent rewrite)
-                if (__ballot(mine && !grp)) {
+                if (__ballot(mine && !fastc)) {
                     const uint32_t step = w8 ? 8u : (w4 ? 4u : 1u);
                     const uint32_t last = ml - step;
-                    const bool slow = mine && !grp;
+                    const bool slow = mine && !fastc;
                     for (uint32_t o = 0; __ballot(slow && o < ml); o += step) {
                         if (STATS) sc[PS_MATCH_ITERS]++;
                         if (slow && o < ml) {
