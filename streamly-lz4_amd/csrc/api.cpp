@@ -14,8 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -39,6 +41,92 @@ static int fail(int code, const char *fmt, ...)
             return fail(MI355LZ4_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// ---------------------------------------------------------------------------
+// Host copy pool: the staging copies between pageable caller memory and the
+// pinned buffers are what bounds the host-buffer API (one thread moves ~10 GB/s,
+// the Gen5 x16 link ~55 GB/s), so they are spread over a few threads.
+// MI355LZ4_COPY_THREADS overrides the count (default 8, 1 = no helper threads).
+// ---------------------------------------------------------------------------
+struct CopyTask { uint8_t *dst; const uint8_t *src; size_t n; };
+
+class CopyPool {
+public:
+    CopyPool()
+    {
+        int n = 8;
+        if (const char *e = getenv("MI355LZ4_COPY_THREADS")) n = atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)n > hw) n = (int)hw;
+        if (n < 1) n = 1;
+        for (int i = 1; i < n; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cvWork_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    // run all tasks; the calling thread works too; returns when every byte is copied
+    void run(const std::vector<CopyTask> &tasks)
+    {
+        if (tasks.empty()) return;
+        if (workers_.empty() || tasks.size() == 1) {
+            for (const CopyTask &t : tasks) if (t.n) memcpy(t.dst, t.src, t.n);
+            return;
+        }
+        std::lock_guard<std::mutex> one(callers_);   // one batch of tasks at a time
+        std::unique_lock<std::mutex> lk(m_);
+        tasks_ = &tasks; next_ = 0; pending_ = tasks.size();
+        cvWork_.notify_all();
+        while (next_ < tasks.size()) {
+            const CopyTask t = tasks[next_++];
+            lk.unlock();
+            if (t.n) memcpy(t.dst, t.src, t.n);
+            lk.lock();
+            pending_--;
+        }
+        cvDone_.wait(lk, [this] { return pending_ == 0; });
+        tasks_ = nullptr;
+    }
+    // one large range, cut into slices
+    void copy(uint8_t *dst, const uint8_t *src, size_t n)
+    {
+        static const size_t kSlice = (size_t)1 << 20;
+        std::vector<CopyTask> t;
+        for (size_t off = 0; off < n; off += kSlice) t.push_back({dst + off, src + off, (n - off < kSlice) ? n - off : kSlice});
+        run(t);
+    }
+
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cvWork_.wait(lk, [this] { return stop_ || (tasks_ && next_ < tasks_->size()); });
+            if (stop_) return;
+            while (tasks_ && next_ < tasks_->size()) {
+                const CopyTask t = (*tasks_)[next_++];
+                lk.unlock();
+                if (t.n) memcpy(t.dst, t.src, t.n);
+                lk.lock();
+                if (--pending_ == 0) cvDone_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, callers_;
+    std::condition_variable cvWork_, cvDone_;
+    const std::vector<CopyTask> *tasks_ = nullptr;
+    size_t next_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+static CopyPool &copy_pool()
+{
+    static CopyPool *pool = new CopyPool();     // leaked on purpose: no thread joins during process teardown
+    return *pool;
+}
 
 // ---------------------------------------------------------------------------
 // engine
@@ -85,7 +173,7 @@ static void pin_release(DevBuf &b) { if (b.p) hipHostFree(b.p); b.p = nullptr; b
 // the CPU memcpy of chunk i+1 overlaps the DMA of chunk i.
 // A plain hipMemcpy of pageable memory runs at a few GB/s; this keeps the link busy.
 // ---------------------------------------------------------------------------
-static const size_t kStageChunk = (size_t)8 << 20;
+static const size_t kStageChunk = (size_t)16 << 20;
 
 static int h2d_staged(mi355lz4_ctx *c, void *dstDev, const uint8_t *srcHost, size_t bytes)
 {
@@ -95,7 +183,7 @@ static int h2d_staged(mi355lz4_ctx *c, void *dstDev, const uint8_t *srcHost, siz
     uint8_t *stage = (uint8_t *)c->pinIn.p;
     for (size_t off = 0; off < bytes; off += kStageChunk) {
         const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
-        memcpy(stage + off, srcHost + off, n);
+        copy_pool().copy(stage + off, srcHost + off, n);
         HIP_TRY(hipMemcpyAsync((uint8_t *)dstDev + off, stage + off, n, hipMemcpyHostToDevice, c->stream));
     }
     return 0;
@@ -121,7 +209,7 @@ static int d2h_staged(mi355lz4_ctx *c, uint8_t *dstHost, const void *srcDev, siz
         const size_t off = k * kStageChunk;
         const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
         if (!rc && hipEventSynchronize(ev[k]) != hipSuccess) rc = fail(MI355LZ4_E_HIP, "hipEventSynchronize failed");
-        if (!rc) memcpy(dstHost + off, stage + off, n);
+        if (!rc) copy_pool().copy(dstHost + off, stage + off, n);
         hipEventDestroy(ev[k]);
     }
     return rc;
@@ -443,10 +531,13 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
     uint8_t *stage = (uint8_t *)c->pinIn.p;
     {
         size_t sent = 0;                       // staging bytes already handed to the DMA engine
+        std::vector<CopyTask> tasks;
         for (int i = 0; i < nBlocks; i++) {
-            if (srcLen[i] > 0) memcpy(stage + offs[(size_t)i], src[i], (size_t)srcLen[i]);
+            if (srcLen[i] > 0) tasks.push_back({stage + offs[(size_t)i], src[i], (size_t)srcLen[i]});
             const size_t filled = (i + 1 < nBlocks) ? (size_t)offs[(size_t)i + 1] : total;
             if (filled - sent >= kStageChunk || i + 1 == nBlocks) {
+                copy_pool().run(tasks);
+                tasks.clear();
                 HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + sent, stage + sent, filled - sent, hipMemcpyHostToDevice, c->stream));
                 sent = filled;
             }
