@@ -547,3 +547,46 @@ def test_linked_streams_error_is_local(engine, oracle):
         assert res[lo + j] == code, (j, res[lo + j], code)
         if code > 0:
             dict_bytes = dec
+
+
+def test_linked_streams_fuzz_codes(engine, oracle):
+    """Random single-byte corruptions anywhere in reference-linked streams: every block's result (size or
+    negative code) and every decoded byte equals the oracle's linked decode of the same bytes."""
+    rng = random.Random(2024)
+    base = []
+    for s in range(4):
+        kind = ["text", "lzsynth", "text", "lzsynth"][s]
+        bl = [8192, 16384, 65536, 4096][s]
+        d = oracle.gen(kind, 3, bl, first_block=500 + 10 * s).tobytes()
+        if s == 2:
+            pat = d[:2500]
+            d = (pat * (len(d) // len(pat) + 1))[: len(d)]
+        base.append(oracle.frame_compress(d, bl, 1, 8, True))
+    frs, expect = [], []
+    for trial in range(120):
+        fr = bytearray(base[trial % 4])
+        blocks = split_blocks(bytes(fr))
+        # corrupt one payload byte of block 1 or 2 (never a header: header errors are a separate test)
+        bi = rng.choice([1, 2])
+        start = sum(len(b) for b in blocks[:bi]) + 8
+        pos = start + rng.randrange(len(blocks[bi]) - 8)
+        fr[pos] ^= 1 << rng.randrange(8)
+        frs.append(bytes(fr))
+        # oracle: the reference's linked semantics, block by block
+        dict_bytes, res, outs = None, [], []
+        for b in split_blocks(bytes(fr)):
+            cap = int.from_bytes(b[4:8], "little")
+            code, dec = oracle.decompress_block(b[8:], cap, dict_bytes)
+            res.append(code)
+            outs.append(dec if code >= 0 else None)
+            if code > 0:
+                dict_bytes = dec
+        expect.append((res, outs))
+    out, res, ulen, first = _decode_streams(engine, frs, "streams")
+    for t, (eres, eouts) in enumerate(expect):
+        lo = first[t]
+        assert res[lo:lo + 3] == eres, (t, res[lo:lo + 3], eres)
+        for j in range(3):
+            if eouts[j] is not None:
+                o = sum(ulen[:lo + j])
+                assert out[o:o + len(eouts[j])] == eouts[j], (t, j)
