@@ -312,12 +312,14 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 }
                 const int lastEnd = pEnd;
                 const bool sel = (selm >> lane) & 1ull;
-                // the next window starts at lastEnd: fetch its bytes now, under the emit below
-                pfPos = lastEnd;
-                pfV8 = (lastEnd + lane < mfl) ? *(const u64_unaligned *)(src + lastEnd + lane) : 0ull;
+                // the next window starts at the end of the last match, or at the end of this window when the
+                // match ends inside it: the positions after it were probed just now and all missed
+                const int nextP = max(lastEnd, p0 + LZ4_WAVE);
+                pfPos = nextP;
+                pfV8 = (nextP + lane < mfl) ? *(const u64_unaligned *)(src + nextP + lane) : 0ull;
                 ENC_LAP(2);
                 // ---- table: the probed positions outside the selected matches (:998) ----
-                if (valid && !covered && myPos < lastEnd) table[h] = (TabT)myPos;
+                if (valid && !covered && myPos < nextP) table[h] = (TabT)myPos;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 const int myEnd = myPos + (int)myMl;
                 ENC_LAP(3);
@@ -346,7 +348,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     qCnt += k;
                 }
                 anchor = lastEnd;
-                p = lastEnd;
+                p = nextP;
                 missAcc = miss0;
                 ENC_LAP(5);
 #ifdef ENC_STATS
