@@ -43,7 +43,7 @@ namespace lz4dev {
 #define PAR_NODES 512       // speculative token candidates per window (8 per lane)
 #define PAR_WIN 1024        // bytes of compressed stream staged per window (16 per lane)
 #ifndef PAR_RING
-#define PAR_RING 7168       // LDS output staging
+#define PAR_RING 6144       // LDS output staging (8.3 KiB of LDS per wave in all: 19 waves per CU)
 #endif
 #ifndef PAR_HIST
 #define PAR_HIST 2048       // bytes of history kept in the ring across a slide
@@ -52,7 +52,7 @@ namespace lz4dev {
 #define PAR_BATCH_OUT 2560  // max output bytes of one batch
 #endif
 #ifndef PAR_WAVES
-#define PAR_WAVES 4         // occupancy target (waves per SIMD) the register allocator is held to
+#define PAR_WAVES 5         // occupancy target (waves per SIMD) the register allocator is held to (<= 102 VGPRs)
 #endif
 
 // jump[] is the successor table of step 3.  Entries are BYTE offsets into jump[] itself (2 x node
@@ -149,7 +149,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     const uint8_t *dictEnd = DICT ? dict + dictLen : dst;
     const int dictLo = DICT ? -(int)min(dictLen, 65535u) : 0;
 
-    const int lane = lane_id();
+    int lane = lane_id();
     const int iend = srcLen;
     const uint32_t A = (uint32_t)((uintptr_t)dst & 15);   // ring index of output position p is p - ringBase + A
     int ip = 0, op = 0;
@@ -531,8 +531,17 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         if (r == SEQ_CONTINUE && (!st.fast || iend - st.ip < 64 || cap - st.op < 128))
             r = decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
         lap(PS_T_SEQ);
+        r = uni(r);
         if (r != SEQ_CONTINUE) { publish(); return r; }
-        ip = st.ip; op = st.op;
+        ip = uni(st.ip); op = uni(st.op);                 // read back through memory: tell the compiler they are uniform
+        // Nothing lane-private has to survive the call: the lane id is re-read (an opaque definition, so that
+        // the values derived from it are rebuilt instead of being kept in registers across the call) and the
+        // window is fetched again.  decode_seq_run clobbers v0..v79; every VGPR that lives across the call
+        // sits above that and used to push the kernel to 124 VGPRs = 4 waves per SIMD.
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        wbase = (uintptr_t)(src + ip) & ~(uintptr_t)15;
+        wnext = fetch_window(wbase);
+        winStale = true;
         // reload the ring's history from global memory
         wave_fence();
         ringBase = (op > PAR_HIST) ? ((op - PAR_HIST) & ~15) : 0;
