@@ -24,9 +24,11 @@ namespace lz4dev {
 // external dictionary, cbits/lz4.c:1883-1911): byte k of the source is
 // dict[dictLen + match + k] while match + k < 0, dst[match + k] afterwards.
 // offset == 0 yields zero bytes, as v1.9.3 does (cbits/lz4.c:2122-2130).
-__device__ __forceinline__ void wave_copy_match(uint8_t *dst, int op, int match, uint32_t ml,
-                                                uint32_t offset, const uint8_t *dict, uint32_t dictLen)
+__device__ __forceinline__ void wave_copy_match(uint8_t *dstGeneric, int op, int match, uint32_t ml,
+                                                uint32_t offset, const uint8_t *dictGeneric, uint32_t dictLen)
 {
+    LZ4_GLOBAL uint8_t *dst = as_global(dstGeneric);              // output and dictionary are global memory
+    const LZ4_GLOBAL uint8_t *dict = as_global(dictGeneric);
     const uint32_t lane = (uint32_t)lane_id();
     wave_fence();
     if (offset == 0) {

@@ -72,11 +72,11 @@ struct InWindow {
         const uint8_t *q = (const uint8_t *)(base + 4u * (uint32_t)lane_id());
         uint32_t v = 0;
         if (q >= lo && q + 4 <= hi) {
-            v = *(const uint32_t *)q;
+            v = *as_global((const uint32_t *)q);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (q + k >= lo && q + k < hi) v |= (uint32_t)q[k] << (8 * k);
+                if (q + k >= lo && q + k < hi) v |= (uint32_t)as_global(q)[k] << (8 * k);
         }
         w = v;
     }
@@ -97,21 +97,25 @@ struct InWindow {
 // Wave-parallel byte copy, non-overlapping (literal runs: compressed stream <-> raw bytes).
 // Long runs (incompressible data is one run per block) move 16 bytes per lane with aligned
 // stores; short runs one byte per lane.
-__device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
+typedef uint32_t dev_v4 __attribute__((ext_vector_type(4)));
+typedef dev_v4 dev_v4u __attribute__((aligned(1)));
+
+// Every buffer these helpers are handed is device global memory (never LDS): saying so keeps the
+// accesses global_load/global_store instead of flat_*.
+__device__ __forceinline__ void wave_copy_bytes(uint8_t *dstGeneric, const uint8_t *srcGeneric, uint32_t n)
 {
+    LZ4_GLOBAL uint8_t *dst = as_global(dstGeneric);
+    const LZ4_GLOBAL uint8_t *src = as_global(srcGeneric);
     const uint32_t lane = (uint32_t)lane_id();
     if (n >= 512u) {
-        const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)dstGeneric & 15u)) & 15u);
         if (lane < head) dst[lane] = src[lane];
         const uint32_t body = (n - head) >> 4;
-        uint4 *d16 = (uint4 *)(dst + head);
-        const uint8_t *s16 = src + head;
+        LZ4_GLOBAL dev_v4 *d16 = (LZ4_GLOBAL dev_v4 *)(dst + head);
+        const LZ4_GLOBAL uint8_t *s16 = src + head;
 #pragma unroll 2
-        for (uint32_t i = lane; i < body; i += LZ4_WAVE) {
-            uint4 v;
-            __builtin_memcpy(&v, s16 + ((size_t)i << 4), 16);     // unaligned 16-byte load
-            d16[i] = v;
-        }
+        for (uint32_t i = lane; i < body; i += LZ4_WAVE)
+            d16[i] = *(const LZ4_GLOBAL dev_v4u *)(s16 + ((size_t)i << 4));     // unaligned 16-byte load
         const uint32_t done = head + (body << 4);
         if (done + lane < n) dst[done + lane] = src[done + lane];
         return;
