@@ -296,19 +296,31 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     pfPos = -1;
                     continue;
                 }
+                // The loop is scalar (one v_readlane per selected match); what each lane needs from it -- the end of
+                // the selected match before it -- is fetched afterwards with one cross-lane read.
                 uint64_t selm = 0;
-                int prevEnd = anchor;            // per lane: end of the previous selected match (my literal start)
-                bool covered = false;            // my position lies strictly inside a selected match
                 int pEnd = anchor;
-                while (hitm) {
-                    const int k = (int)__builtin_ctzll(hitm);
+                for (uint64_t hm = hitm; hm;) {
+                    const int k = (int)__builtin_ctzll(hm);
                     const int endk = p0 + k + (int)__builtin_amdgcn_readlane((int)myMl, k);
                     selm |= 1ull << k;
-                    if (lane == k) prevEnd = pEnd;
-                    covered = covered || (lane > k && myPos < endk);
                     pEnd = endk;
                     const int sh = endk - p0;
-                    hitm = (sh >= LZ4_WAVE) ? 0ull : (hitm & (~0ull << sh));
+                    hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
+                }
+                int prevEnd = anchor;            // selected lanes: end of the previous selected match (my literal start)
+                bool covered = false;            // my position lies strictly inside a selected match
+                {
+                    const bool selMe = (selm >> lane) & 1ull;
+                    const uint64_t lowerIncl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                    // selected lane: the selected lane before me; any other lane: the last selected lane below me
+                    const uint64_t m = selm & (lowerIncl >> 1);          // selected lanes strictly below me
+                    const int from = m ? 63 - (int)__builtin_clzll(m) : -1;
+                    const int endFrom = par_free_bperm(myPos + (int)myMl, from & 63);
+                    if (from >= 0) {
+                        if (selMe) prevEnd = endFrom;
+                        else covered = myPos < endFrom;
+                    }
                 }
                 const int lastEnd = pEnd;
                 const bool sel = (selm >> lane) & 1ull;
