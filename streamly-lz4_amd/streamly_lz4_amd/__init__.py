@@ -12,6 +12,7 @@ callers that want device memory / streams / torch.distributed; this module
 itself needs only ctypes and numpy.
 """
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -237,6 +238,20 @@ class Engine:
             raise LZ4Error((lib.slz4_last_error() or b"").decode())
         self.ctx = C.c_void_p(lib.slz4_engine_ctx(self._h))
         self.device = device
+        # The engine creates a non-blocking stream of its own.  The tensors this binding is handed are produced
+        # and consumed by torch on torch's current stream, so the binding launches there: a `torch.zeros(...)`
+        # followed by a decode into that tensor is then ordered without an explicit synchronisation.
+        self._on_torch_stream = False
+        self._follow_torch()
+
+    def _follow_torch(self):
+        """Launch on torch's current stream once torch is in the process (it may be imported after the engine)."""
+        if self._on_torch_stream:
+            return
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            self.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            self._on_torch_stream = True
 
     def close(self):
         if self._h:
@@ -263,6 +278,7 @@ class Engine:
 
     # ---- timing on the engine's own stream ---------------------------------
     def record(self, ev):
+        self._follow_torch()
         _check(lib.mi355lz4_event_record(self.ctx, ev.h), "event_record")
 
     @staticmethod
@@ -273,23 +289,27 @@ class Engine:
 
     # ---- device-resident batched API (torch uint8/int32/int64 CUDA tensors) ----
     def generate(self, kind, dst, block_len, n_blocks, first_block=0, block_step=1, lit_max=16, off_max=2048):
+        self._follow_torch()
         k = {"random": 0, "lzsynth": 1, "text": 2}[kind]
         _check(lib.mi355lz4_generate_device(self.ctx, k, _dptr(dst), int(block_len), int(n_blocks), int(first_block),
                                             int(block_step), int(lit_max), int(off_max)), "generate_device")
 
     def compress_batch_device(self, src, n_blocks, max_block_len, slots, slot_stride_, framed_len, accel=1,
                               header_kind=8, src_off=None, src_len=None, block_stride=None):
+        self._follow_torch()
         _check(lib.mi355lz4_compress_batch_device(
             self.ctx, _dptr(src), _dptr(src_off), _dptr(src_len),
             int(max_block_len if block_stride is None else block_stride), int(max_block_len), int(n_blocks),
             int(accel), int(header_kind), _dptr(slots), int(slot_stride_), _dptr(framed_len)), "compress_batch_device")
 
     def compact_device(self, slots, slot_stride_, framed_len, n_blocks, dense, dense_cap, dense_off):
+        self._follow_torch()
         _check(lib.mi355lz4_compact_device(self.ctx, _dptr(slots), int(slot_stride_), _dptr(framed_len), int(n_blocks),
                                            _dptr(dense), int(dense_cap), _dptr(dense_off)), "compact_device")
 
     def decompress_batch_device(self, framed, framed_len, block_off, n_blocks, out, out_off, result, header_kind=8,
                                 fixed_uncomp=0, linked=False, out_cap=None):
+        self._follow_torch()
         _check(lib.mi355lz4_decompress_batch_device(
             self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
             int(fixed_uncomp), int(bool(linked)), _dptr(out), _dptr(out_off), _dptr(out_cap), _dptr(result)),
@@ -297,6 +317,7 @@ class Engine:
 
     def decompress_streams_device(self, framed, framed_len, block_off, n_blocks, stream_first, n_streams, out,
                                   out_off, result, header_kind=8, fixed_uncomp=0, out_cap=None):
+        self._follow_torch()
         """Linked streams: stream s = blocks [stream_first[s], stream_first[s+1]) (int32 device tensor)."""
         _check(lib.mi355lz4_decompress_streams_device(
             self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
@@ -304,10 +325,12 @@ class Engine:
             _dptr(result)), "decompress_streams_device")
 
     def index_device(self, framed, framed_len, block_off, n_blocks, out_off, header_kind=8, fixed_uncomp=0):
+        self._follow_torch()
         _check(lib.mi355lz4_index_device(self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks),
                                          int(header_kind), int(fixed_uncomp), _dptr(out_off)), "index_device")
 
     def interleave_device(self, local, local_off, n_local, rank, n_ranks, global_buf, global_off):
+        self._follow_torch()
         _check(lib.mi355lz4_interleave_device(self.ctx, _dptr(local), _dptr(local_off), int(n_local), int(rank),
                                               int(n_ranks), _dptr(global_buf), _dptr(global_off)), "interleave_device")
 
