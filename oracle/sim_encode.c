@@ -1,6 +1,6 @@
 // Development aid: CPU simulation of the wave-parallel match finder in
 // streamly-lz4_amd/csrc/encode_wave.hpp (sizes only), to tune ratio without a GPU.
-// Build: gcc -O2 -I oracle scripts/sim_encode.c oracle/lz4_oracle.c -o /tmp/sim_encode
+// Build: gcc -O2 -I oracle oracle/sim_encode.c oracle/lz4_oracle.c -o /tmp/sim_encode
 #include "lz4_oracle.h"
 #include <stdio.h>
 #include <stdlib.h>

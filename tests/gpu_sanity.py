@@ -1,6 +1,6 @@
 """Quick end-to-end sanity + timing on a GPU box (development aid, not a test).
 
-    python scripts/gpu_sanity.py [n_blocks] [block_len]
+    python tests/gpu_sanity.py [n_blocks] [block_len]
 """
 import os
 import sys
