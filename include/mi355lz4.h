@@ -173,6 +173,14 @@ int mi355lz4_decompress_batch(mi355lz4_ctx *ctx, const uint8_t *framedIn, size_t
                               int fixedUncomp, int linked, const uint8_t *dict, int dictLen, uint8_t *out,
                               size_t cap, size_t *outLen, int32_t *blockLen, int maxBlocks, int *nBlocks);
 
+/* Host-buffer form of mi355lz4_decompress_streams_device: framedIn holds the blocks
+ * of nStreams linked streams back to back, stream s = blocks
+ * [streamFirst[s], streamFirst[s+1]) (host array, ascending).  Blocks outside
+ * every stream are decoded on their own.  Otherwise as mi355lz4_decompress_batch. */
+int mi355lz4_decompress_streams(mi355lz4_ctx *ctx, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                int fixedUncomp, const int32_t *streamFirst, int nStreams, uint8_t *out,
+                                size_t cap, size_t *outLen, int32_t *blockLen, int maxBlocks, int *nBlocks);
+
 /* ---- synthetic inputs (bench / test support; SURVEY.md 8d generators) ---
  * kind: 0 = xorshift64* random, 1 = lzsynth(litMax, offMax), 2 = text-like.
  * Block i of the batch is seeded by (firstBlock + i * blockStep); it is written

@@ -602,10 +602,40 @@ extern "C" int mi355lz4_index_host(const uint8_t *framedIn, size_t inLen, int he
     return MI355LZ4_OK;
 }
 
+static int decompress_host(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                           int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
+                           const int32_t *streamFirst, int nStreams,
+                           uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
+                           int maxBlocks, int *nBlocksOut);
+
 extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
                                          int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
                                          uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
                                          int maxBlocks, int *nBlocksOut)
+{
+    return decompress_host(c, framedIn, inLen, headerKind, fixedUncomp, linked, dict, dictLen, nullptr, 0, out, cap,
+                           outLen, blockLen, maxBlocks, nBlocksOut);
+}
+
+extern "C" int mi355lz4_decompress_streams(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                           int fixedUncomp, const int32_t *streamFirst, int nStreams,
+                                           uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
+                                           int maxBlocks, int *nBlocksOut)
+{
+    if (nStreams < 0 || (nStreams > 0 && !streamFirst))
+        return fail(MI355LZ4_E_ARG, "decompress_streams: bad stream table");
+    for (int s = 0; s < nStreams; s++)
+        if (streamFirst[s] < 0 || streamFirst[s + 1] < streamFirst[s])
+            return fail(MI355LZ4_E_ARG, "decompress_streams: stream table is not ascending at %d", s);
+    return decompress_host(c, framedIn, inLen, headerKind, fixedUncomp, 1, nullptr, 0, streamFirst, nStreams, out, cap,
+                           outLen, blockLen, maxBlocks, nBlocksOut);
+}
+
+static int decompress_host(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                           int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
+                           const int32_t *streamFirst, int nStreams,
+                           uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
+                           int maxBlocks, int *nBlocksOut)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
     if (!outLen || !nBlocksOut || maxBlocks < 0) return fail(MI355LZ4_E_ARG, "decompress_batch: bad arguments");
@@ -646,9 +676,18 @@ extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedI
     HIP_TRY(hipMemcpyAsync(c->offA.p, boff.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->offB.p, ooff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t *sfDev = nullptr;
+    if (streamFirst) {
+        if (nStreams == 0 || streamFirst[nStreams] > n)
+            return fail(MI355LZ4_E_ARG, "decompress_streams: the stream table names block %d of %d", nStreams ? streamFirst[nStreams] : 0, n);
+        if ((r = dev_reserve(c->lenA, ((size_t)nStreams + 1) * 4))) return r;
+        HIP_TRY(hipMemcpyAsync(c->lenA.p, streamFirst, ((size_t)nStreams + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        sfDev = (const int32_t *)c->lenA.p;
+    }
     r = decode_device(c, (const uint8_t *)c->in.p, inLen, (const uint64_t *)c->offA.p, n, headerKind, fixedUncomp,
                       linked, (uint8_t *)c->out.p, (const uint64_t *)c->offB.p, nullptr, (int32_t *)c->res.p,
-                      dlen ? (const uint8_t *)c->scratch.p : nullptr, dlen);
+                      dlen ? (const uint8_t *)c->scratch.p : nullptr, dlen, sfDev, nStreams);
     if (r) return r;
     std::vector<int32_t> res((size_t)n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->res.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

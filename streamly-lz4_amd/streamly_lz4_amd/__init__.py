@@ -93,6 +93,8 @@ def _load():
         C.POINTER(C.c_int))
     sig("mi355lz4_decompress_batch", C.c_int, vp, _u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _u8p, C.c_int,
         _u8p, C.c_size_t, C.POINTER(C.c_size_t), _i32p, C.c_int, C.POINTER(C.c_int))
+    sig("mi355lz4_decompress_streams", C.c_int, vp, _u8p, C.c_size_t, C.c_int, C.c_int, _i32p, C.c_int,
+        _u8p, C.c_size_t, C.POINTER(C.c_size_t), _i32p, C.c_int, C.POINTER(C.c_int))
     sig("mi355lz4_generate_device", C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
         C.c_uint32, C.c_uint32)
     sig("mi355lz4_interleave_device", C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp)
@@ -135,7 +137,7 @@ DECLARED_SYMBOLS = [
     "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
     "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
-    "mi355lz4_decompress_batch", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
+    "mi355lz4_decompress_batch", "mi355lz4_decompress_streams", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
     "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
     "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
     "LZ4_compress_fast_continue", "LZ4_decompress_safe_continue",
@@ -375,6 +377,30 @@ class Engine:
                                            C.byref(out_len), blen.ctypes.data_as(_i32p), max(nb.value, 1), C.byref(got))
         if rc != 0 and (raise_on_block_error or rc != -5):
             _check(rc, "decompress_batch")
+        return out[: out_len.value].tobytes(), blen[: got.value].tolist()
+
+    def decompress_streams(self, framed, stream_first, header_kind=8, fixed_uncomp=0, raise_on_block_error=True):
+        """Many linked streams, host buffers: stream s = blocks [stream_first[s], stream_first[s+1]).
+        Returns (decoded bytes, [decoded length or negative code per block])."""
+        src = np.frombuffer(bytes(framed), dtype=np.uint8)
+        max_blocks = src.size // (header_kind + 1) + 1
+        boff = np.zeros(max_blocks + 1, dtype=np.uint64)
+        ulen = np.zeros(max_blocks + 1, dtype=np.int32)
+        nb = C.c_int()
+        _check(lib.mi355lz4_index_host(src.ctypes.data_as(_u8p), src.size, header_kind, fixed_uncomp,
+                                       boff.ctypes.data_as(_u64p), ulen.ctypes.data_as(_i32p), max_blocks, C.byref(nb)),
+               "index_host")
+        cap = int(ulen[: nb.value].astype(np.int64).clip(min=0).sum()) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_size_t()
+        blen = np.zeros(max(nb.value, 1), dtype=np.int32)
+        got = C.c_int()
+        sf = np.asarray(stream_first, dtype=np.int32)
+        rc = lib.mi355lz4_decompress_streams(self.ctx, src.ctypes.data_as(_u8p), src.size, header_kind, fixed_uncomp,
+                                             sf.ctypes.data_as(_i32p), int(sf.size - 1), out.ctypes.data_as(_u8p), cap,
+                                             C.byref(out_len), blen.ctypes.data_as(_i32p), max(nb.value, 1), C.byref(got))
+        if rc != 0 and (raise_on_block_error or rc != -5):
+            _check(rc, "decompress_streams")
         return out[: out_len.value].tobytes(), blen[: got.value].tolist()
 
 

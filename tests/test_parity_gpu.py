@@ -590,3 +590,21 @@ def test_linked_streams_fuzz_codes(engine, oracle):
             if eouts[j] is not None:
                 o = sum(ulen[:lo + j])
                 assert out[o:o + len(eouts[j])] == eouts[j], (t, j)
+
+
+def test_linked_streams_host_api(engine, oracle):
+    """mi355lz4_decompress_streams (host buffers) == the device entry point == the raw data."""
+    datas, frs = [], []
+    for s in range(9):
+        d = oracle.gen("text", 1 + s % 4, 16384, first_block=40 * s).tobytes()
+        datas.append(d)
+        frs.append(oracle.frame_compress(d, 16384, 1, 8, True))
+    blob, boff, first, ulen = _stream_layout(frs)
+    out, blen = engine.decompress_streams(blob, first)
+    assert blen == ulen and out == b"".join(datas)
+    # the table is checked
+    import streamly_lz4_amd as S
+    with pytest.raises(S.LZ4Error):
+        engine.decompress_streams(blob, [0, 5, 3])
+    with pytest.raises(S.LZ4Error):
+        engine.decompress_streams(blob, [0, len(boff) + 1])
