@@ -73,6 +73,16 @@ foreign import ccall safe "mi355lz4.h mi355lz4_decompress_batch"
         -> Ptr Word8 -> CInt -> Ptr Word8 -> CSize -> Ptr CSize -> Ptr Int32
         -> CInt -> Ptr CInt -> IO CInt
 
+-- Many linked streams (each the output of one reference compressChunks pipeline) in one call:
+-- stream s = blocks [streamFirst[s], streamFirst[s+1]).  A server that decompresses many files or
+-- connections at once gathers their resized blocks and calls this instead of one
+-- c_decompressBatch per stream: a single linked stream is walked by one wavefront (slow), many
+-- streams run side by side.
+foreign import ccall safe "mi355lz4.h mi355lz4_decompress_streams"
+    c_decompressStreams
+        :: Ptr C_Engine -> Ptr Word8 -> CSize -> CInt -> CInt -> Ptr Int32 -> CInt
+        -> Ptr Word8 -> CSize -> Ptr CSize -> Ptr Int32 -> CInt -> Ptr CInt -> IO CInt
+
 newEngine :: Int -> IO Engine
 newEngine dev = alloca $ \pp -> do
     rc <- c_create pp (fromIntegral dev)
