@@ -78,13 +78,15 @@ public:
         std::lock_guard<std::mutex> one(callers_);   // one batch of tasks at a time
         std::unique_lock<std::mutex> lk(m_);
         tasks_ = &tasks; next_ = 0; pending_ = tasks.size();
+        grab_ = tasks.size() / ((workers_.size() + 1) * 8) + 1;    // a few grabs per thread: small tasks share a lock trip
         cvWork_.notify_all();
         while (next_ < tasks.size()) {
-            const CopyTask t = tasks[next_++];
+            const size_t lo = next_, hi = (lo + grab_ < tasks.size()) ? lo + grab_ : tasks.size();
+            next_ = hi;
             lk.unlock();
-            if (t.n) memcpy(t.dst, t.src, t.n);
+            for (size_t i = lo; i < hi; i++) if (tasks[i].n) memcpy(tasks[i].dst, tasks[i].src, tasks[i].n);
             lk.lock();
-            pending_--;
+            pending_ -= hi - lo;
         }
         cvDone_.wait(lk, [this] { return pending_ == 0; });
         tasks_ = nullptr;
@@ -106,11 +108,14 @@ private:
             cvWork_.wait(lk, [this] { return stop_ || (tasks_ && next_ < tasks_->size()); });
             if (stop_) return;
             while (tasks_ && next_ < tasks_->size()) {
-                const CopyTask t = (*tasks_)[next_++];
+                const std::vector<CopyTask> &ts = *tasks_;
+                const size_t lo = next_, hi = (lo + grab_ < ts.size()) ? lo + grab_ : ts.size();
+                next_ = hi;
                 lk.unlock();
-                if (t.n) memcpy(t.dst, t.src, t.n);
+                for (size_t i = lo; i < hi; i++) if (ts[i].n) memcpy(ts[i].dst, ts[i].src, ts[i].n);
                 lk.lock();
-                if (--pending_ == 0) cvDone_.notify_all();
+                pending_ -= hi - lo;
+                if (pending_ == 0) cvDone_.notify_all();
             }
         }
     }
@@ -118,7 +123,7 @@ private:
     std::mutex m_, callers_;
     std::condition_variable cvWork_, cvDone_;
     const std::vector<CopyTask> *tasks_ = nullptr;
-    size_t next_ = 0, pending_ = 0;
+    size_t next_ = 0, pending_ = 0, grab_ = 1;
     bool stop_ = false;
 };
 
@@ -173,7 +178,16 @@ static void pin_release(DevBuf &b) { if (b.p) hipHostFree(b.p); b.p = nullptr; b
 // the CPU memcpy of chunk i+1 overlaps the DMA of chunk i.
 // A plain hipMemcpy of pageable memory runs at a few GB/s; this keeps the link busy.
 // ---------------------------------------------------------------------------
-static const size_t kStageChunk = (size_t)16 << 20;
+static size_t stage_chunk()
+{
+    static const size_t v = [] {
+        const char *e = getenv("MI355LZ4_STAGE_CHUNK_MB");
+        const long mb = e ? atol(e) : 16;
+        return (size_t)((mb < 1) ? 1 : (mb > 256 ? 256 : mb)) << 20;
+    }();
+    return v;
+}
+#define kStageChunk (stage_chunk())
 
 static int h2d_staged(mi355lz4_ctx *c, void *dstDev, const uint8_t *srcHost, size_t bytes)
 {
