@@ -40,12 +40,14 @@ import Data.Word (Word8)
 import Foreign.C (CInt(..), CSize(..))
 import Foreign.Marshal.Alloc (alloca)
 import Foreign.Marshal.Array (allocaArray, peekArray, pokeArray)
+import Foreign.Marshal.Utils (copyBytes)
 import Foreign.Ptr (Ptr, nullPtr, plusPtr, castPtr)
 import Foreign.Storable (peek)
 
 import qualified Streamly.Internal.Data.Array.Foreign as Array
 import qualified Streamly.Internal.Data.Array.Foreign.Type as Array
 import qualified Streamly.Internal.Data.Array.Foreign.Mut.Type as MArray
+import qualified Streamly.Internal.Data.Fold as Fold
 import qualified Streamly.Internal.Data.Stream.StreamD as Stream
 
 import Streamly.Internal.LZ4.Config
@@ -134,6 +136,20 @@ compressBatch (Engine eng) cfg speed arrs = do
                    `seq` Array.Array cont (dstBegin `plusPtr` o) (dstBegin `plusPtr` (o + l))
                | (o, l) <- zip offs flens ]
 
+-- | One freshly allocated array holding the given arrays back to back (the reference splices
+-- pairwise with @Array.splice@, Streamly/Internal/LZ4.hs:502; a batch is concatenated in one pass).
+concatArrays :: [Array.Array Word8] -> IO (Array.Array Word8)
+concatArrays arrs = do
+    let total = sum (map Array.byteLength arrs)
+    (MArray.Array cont b_ b bound) <- MArray.newArray (max total 1)
+    let go _ [] = return ()
+        go o (a : as) = do
+            let l = Array.byteLength a
+            Array.asPtrUnsafe (Array.unsafeCast a) $ \p -> copyBytes (b `plusPtr` o) (p :: Ptr Word8) l
+            go (o + l) as
+    go 0 arrs
+    return $ Array.unsafeFreeze (MArray.Array cont b_ (b `plusPtr` total) bound)
+
 -- | Drop-in for @compressChunksD@ (Streamly/Internal/LZ4.hs:353-394).
 compressChunksGPU
     :: MonadIO m
@@ -142,9 +158,7 @@ compressChunksGPU
 compressChunksGPU eng cfg speed0 =
       Stream.concatMap Stream.fromList
     . Stream.mapM (liftIO . compressBatch eng cfg (max speed0 0))
-    . Stream.groupsOf batchBlocks (fmap id toListFold)
-  where
-    toListFold = undefined -- Fold.toList from Streamly.Internal.Data.Fold (import elided)
+    . Stream.groupsOf batchBlocks Fold.toList
 
 -- | Drop-in for @decompressChunksRawD@ (Streamly/Internal/LZ4.hs:539-567): the incoming
 -- arrays are resized blocks; the previous output array is threaded through as the
@@ -177,7 +191,7 @@ decompressChunksRawGPU (Engine eng) cfg (Stream.Stream step0 st0) =
             Stream.Skip st1 -> gather gst st1 k acc
             Stream.Stop -> return (reverse acc, st, True)
     decompressBatch prev batch = do
-        framed <- Array.splice' batch                     -- blocks back to back (concatenation)
+        framed <- concatArrays batch                      -- blocks back to back
         let n = length batch
         -- capacity: sum of the header (or fixed) uncompressed sizes, computed as decompressChunk does
         cap <- sum <$> forM batch (\a -> Array.asPtrUnsafe (Array.unsafeCast a) $ \p ->

@@ -9,7 +9,7 @@
  * This is a restatement written from the algorithm, not a copy: plain index
  * arithmetic on byte arrays, one function per reference stage, each citing the
  * reference lines it follows.  Pinned against the compiled reference
- * (oracle/_ref) by tests/test_oracle_vs_ref.py and against tests/golden/.
+ * (oracle/_ref) by tests/test_oracle.py and against tests/golden/.
  */
 #include "lz4_oracle.h"
 

@@ -210,21 +210,25 @@ static int d2h_staged(mi355lz4_ctx *c, uint8_t *dstHost, const void *srcDev, siz
     if (r) return r;
     uint8_t *stage = (uint8_t *)c->pinOut.p;
     const size_t nChunks = (bytes + kStageChunk - 1) / kStageChunk;
-    std::vector<hipEvent_t> ev(nChunks);
-    for (size_t k = 0; k < nChunks; k++) {
-        const size_t off = k * kStageChunk;
-        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
-        HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-        HIP_TRY(hipMemcpyAsync(stage + off, (const uint8_t *)srcDev + off, n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(ev[k], c->stream));
-    }
+    std::vector<hipEvent_t> ev(nChunks, nullptr);
     int rc = 0;
+    size_t issued = 0;
+    for (size_t k = 0; k < nChunks && !rc; k++) {
+        const size_t off = k * kStageChunk;
+        const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
+        if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess ||
+            hipMemcpyAsync(stage + off, (const uint8_t *)srcDev + off, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(ev[k], c->stream) != hipSuccess)
+            rc = fail(MI355LZ4_E_HIP, "d2h_staged: copy of chunk %zu could not be queued", k);
+        else
+            issued = k + 1;
+    }
     for (size_t k = 0; k < nChunks; k++) {
         const size_t off = k * kStageChunk;
         const size_t n = (bytes - off < kStageChunk) ? bytes - off : kStageChunk;
-        if (!rc && hipEventSynchronize(ev[k]) != hipSuccess) rc = fail(MI355LZ4_E_HIP, "hipEventSynchronize failed");
-        if (!rc) copy_pool().copy(dstHost + off, stage + off, n);
-        hipEventDestroy(ev[k]);
+        if (!rc && k < issued && hipEventSynchronize(ev[k]) != hipSuccess) rc = fail(MI355LZ4_E_HIP, "hipEventSynchronize failed");
+        if (!rc && k < issued) copy_pool().copy(dstHost + off, stage + off, n);
+        if (ev[k]) hipEventDestroy(ev[k]);
     }
     return rc;
 }
@@ -261,8 +265,9 @@ extern "C" int mi355lz4_create(mi355lz4_ctx **out, int device)
     mi355lz4_ctx *c = new (std::nothrow) mi355lz4_ctx();
     if (!c) return fail(MI355LZ4_E_ARG, "out of host memory");
     c->device = device;
-    HIP_TRY(hipSetDevice(device));
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete c; return fail(MI355LZ4_E_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(MI355LZ4_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->ownStream = true;
     *out = c;
@@ -301,7 +306,7 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -375,9 +380,11 @@ extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, si
 {
     if (!c || nBlocks < 0 || !denseOff) return fail(MI355LZ4_E_ARG, "compact_device: bad arguments");
     if (nBlocks > 0 && (!slots || !framedLen || !dense)) return fail(MI355LZ4_E_ARG, "compact_device: null pointer");
-    (void)denseCap; // the caller sizes dense for the worst case (nBlocks * slotStride)
     HIP_TRY(hipSetDevice(c->device));
-    launch_compact(slots, slotStride, framedLen, nBlocks, dense, denseOff, c->stream);
+    // The total is only known on the device: the copy kernel never writes at or past denseCap (blocks that
+    // do not fit are skipped), and denseOff[nBlocks] still reports the bytes the full stream needs, so a
+    // caller that sized `dense` below the worst case compares denseOff[nBlocks] with denseCap.
+    launch_compact(slots, slotStride, framedLen, nBlocks, dense, denseCap, denseOff, c->stream);
     return check_launch("compact launch");
 }
 
@@ -400,8 +407,6 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.streamFirst = streamFirst; a.nStreams = nStreams;
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
-    else if (c->decoder == 3)
-        launch_decode_par2(a, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
     if (linked) launch_decode_fixup_linked(a, c->stream);

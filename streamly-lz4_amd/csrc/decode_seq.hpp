@@ -75,7 +75,11 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
     const bool useDict = (dict != nullptr) && dictLen > 0;
     const bool checkOffset = dictLen < 65536u;                 // cbits/lz4.c:1764
     int ip = st.ip, op = st.op;
-    uint32_t token = 0, ll = 0, ml = 0, offset = 0, s = 0;
+    // Lengths are 64-bit: a run of 0xFF length bytes in a multi-megabyte block reaches 2^31 and more, and the
+    // reference compares them as size_t (cbits/lz4.c:1811-1818); the 255-run itself accumulates in 32 bits
+    // (read_variable_length returns unsigned, :1707-1729).
+    uint32_t token = 0, offset = 0, s = 0, acc = 0;
+    int64_t ll = 0, ml = 0;
     int match = 0;
     bool fast = st.fast;
     int budget = maxSeq;
@@ -95,50 +99,53 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
             budget--;
         }
         token = rd(ip); ip++;
-        ll = token >> 4;
+        ll = (int64_t)(token >> 4);
 
         if (fast) {
             // ---------------- fast loop, :1797-1924 ----------------
             if (ll == 15) {
                 if (ip >= iend - 15) goto error;                 // :1809-1810 (initial_error)
-                do { s = rd(ip); ip++; ll += s; } while (s == 255 && ip < iend - 15);
-                if (op + (int)ll > oend - 32 || ip + (int)ll > iend - 32) { fast = false; goto safe_literal_copy; } // :1818
+                acc = 0;
+                do { s = rd(ip); ip++; acc += s; } while (s == 255 && ip < iend - 15);
+                ll += (int64_t)acc;
+                if (op + ll > (int64_t)oend - 32 || ip + ll > (int64_t)iend - 32) { fast = false; goto safe_literal_copy; } // :1818
             } else {
                 if (ip > iend - 17) { fast = false; goto safe_literal_copy; } // :1831
             }
-            wave_copy_bytes(dst + op, src + ip, ll);
+            wave_copy_bytes(dst + op, src + ip, (uint32_t)ll);
             ip += (int)ll; op += (int)ll;
             offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;        // :1844
             match = op - (int)offset;
             ml = token & 15;
             if (ml == 15) {
                 if (checkOffset && match + (int)dictLen < 0) goto error;      // :1853
-                do { s = rd(ip); ip++; ml += s; if (ip >= iend - 4) goto error; } while (s == 255); // :1854-1855
-                ml += LZ4_MINMATCH;
-                if (op + (int)ml >= oend - 64) { fast = false; goto safe_match_copy; } // :1858
+                acc = 0;
+                do { s = rd(ip); ip++; acc += s; if (ip >= iend - 4) goto error; } while (s == 255); // :1854-1855
+                ml += (int64_t)acc + LZ4_MINMATCH;
+                if (op + ml >= (int64_t)oend - 64) { fast = false; goto safe_match_copy; } // :1858
             } else {
                 ml += LZ4_MINMATCH;
-                if (op + (int)ml >= oend - 64) { fast = false; goto safe_match_copy; } // :1863
+                if (op + ml >= (int64_t)oend - 64) { fast = false; goto safe_match_copy; } // :1863
             }
             if (checkOffset && match + (int)dictLen < 0) goto error;          // :1881
             if (match < 0) {
                 if (!useDict) goto error;
-                if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;       // :1884-1889
+                if (op + ml > (int64_t)oend - LZ4_LASTLITERALS) goto error;   // :1884-1889
             }
-            wave_copy_match(dst, op, match, ml, offset, dict, dictLen);
+            wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
             op += (int)ml;
             continue;
         }
 
         // ---------------- safe loop, :1929-2151 ----------------
         if (ll != 15 && ip < iend - 16 && op <= oend - 32) {                  // shortcut :1944-1974
-            wave_copy_bytes(dst + op, src + ip, ll);
+            wave_copy_bytes(dst + op, src + ip, (uint32_t)ll);
             op += (int)ll; ip += (int)ll;
             ml = token & 15;
             offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;
             match = op - (int)offset;
             if (ml != 15 && offset >= 8 && match >= 0) {                      // :1959-1969
-                wave_copy_match(dst, op, match, ml + LZ4_MINMATCH, offset, dict, dictLen);
+                wave_copy_match(dst, op, match, (uint32_t)ml + LZ4_MINMATCH, offset, dict, dictLen);
                 op += (int)ml + LZ4_MINMATCH;
                 continue;
             }
@@ -146,34 +153,38 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
         }
         if (ll == 15) {
             if (ip >= iend - 15) goto error;                                  // :1979-1980
-            do { s = rd(ip); ip++; ll += s; } while (s == 255 && ip < iend - 15);
+            acc = 0;
+            do { s = rd(ip); ip++; acc += s; } while (s == 255 && ip < iend - 15);
+            ll += (int64_t)acc;
         }
     safe_literal_copy:
-        if (op + (int)ll > oend - LZ4_MFLIMIT || ip + (int)ll > iend - (2 + 1 + LZ4_LASTLITERALS)) { // :1991
-            if (ip + (int)ll != iend || op + (int)ll > oend) goto error;      // :2031-2036
-            wave_copy_bytes(dst + op, src + ip, ll);
+        if (op + ll > (int64_t)oend - LZ4_MFLIMIT || ip + ll > (int64_t)iend - (2 + 1 + LZ4_LASTLITERALS)) { // :1991
+            if (ip + ll != (int64_t)iend || op + ll > (int64_t)oend) goto error; // :2031-2036
+            wave_copy_bytes(dst + op, src + ip, (uint32_t)ll);
             ip += (int)ll; op += (int)ll;
             break;                                                            // :2046
         }
-        wave_copy_bytes(dst + op, src + ip, ll);                              // :2050
+        wave_copy_bytes(dst + op, src + ip, (uint32_t)ll);                    // :2050
         ip += (int)ll; op += (int)ll;
         offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;                         // :2055
         match = op - (int)offset;
         ml = token & 15;
     copy_match:
         if (ml == 15) {
-            do { s = rd(ip); ip++; ml += s; if (ip >= iend - 4) goto error; } while (s == 255); // :2064-2065
+            acc = 0;
+            do { s = rd(ip); ip++; acc += s; if (ip >= iend - 4) goto error; } while (s == 255); // :2064-2065
+            ml += (int64_t)acc;
         }
         ml += LZ4_MINMATCH;
     safe_match_copy:
         if (checkOffset && match + (int)dictLen < 0) goto error;              // :2073
         if (match < 0) {
             if (!useDict) goto error;
-            if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;           // :2076-2079
-        } else if (op + (int)ml > oend - 12) {                                // :2137
-            if (op + (int)ml > oend - LZ4_LASTLITERALS) goto error;           // :2139
+            if (op + ml > (int64_t)oend - LZ4_LASTLITERALS) goto error;       // :2076-2079
+        } else if (op + ml > (int64_t)oend - 12) {                            // :2137
+            if (op + ml > (int64_t)oend - LZ4_LASTLITERALS) goto error;       // :2139
         }
-        wave_copy_match(dst, op, match, ml, offset, dict, dictLen);
+        wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
         op += (int)ml;
     }
     wave_fence();

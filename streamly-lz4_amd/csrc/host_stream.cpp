@@ -128,7 +128,8 @@ private:
         int r = mi355lz4_compress_batch(eng_.ctx(), ptrs.data(), lens.data(), n, speed_, meta, framed.data(), cap,
                                         &outLen, flen.data(), status.data());
         if (r != MI355LZ4_OK) {
-            for (int i = 0; i < n; i++)
+            // status[] is only filled when the call got as far as the per-block results
+            for (int i = 0; r == MI355LZ4_E_BLOCK && i < n; i++)
                 if (status[(size_t)i] <= 0)                                     // :257-260
                     throw Error("compressChunk: c_compressFastContinue failed. uncompLenC: " +
                                 std::to_string(lens[(size_t)i]) + "compLenC: " + std::to_string(status[(size_t)i]));

@@ -49,10 +49,9 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
-void launch_decode_par2(const DecodeArgs &a, hipStream_t s);
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
-                    uint8_t *dense, uint64_t *denseOff, hipStream_t s);
+                    uint8_t *dense, size_t denseCap, uint64_t *denseOff, hipStream_t s);
 void launch_interleave(const uint8_t *local, const uint64_t *localOff, int nLocal, int rank, int nRanks,
                        uint8_t *global, const uint64_t *globalOff, hipStream_t s);
 void launch_index(const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff, int nBlocks,

@@ -11,7 +11,6 @@
 
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
-#include "decode_par2.hpp"
 #include "encode_wave.hpp"
 
 using namespace lz4dev;
@@ -143,20 +142,21 @@ __device__ __forceinline__ void wg_copy_bytes(uint8_t *dst, const uint8_t *src, 
 
 __global__ __launch_bounds__(256) void k_copy_slots(const uint8_t *slots, size_t slotStride,
                                                     const int32_t *framedLen, const uint64_t *denseOff,
-                                                    uint8_t *dense)
+                                                    uint8_t *dense, uint64_t denseCap)
 {
     const int blk = (int)blockIdx.x;
     const int n = framedLen[blk];
-    if (n > 0) wg_copy_bytes(dense + denseOff[blk], slots + (size_t)blk * slotStride, (uint64_t)n);
+    const uint64_t at = denseOff[blk];
+    if (n > 0 && at + (uint64_t)n <= denseCap) wg_copy_bytes(dense + at, slots + (size_t)blk * slotStride, (uint64_t)n);
 }
 
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
-                    uint8_t *dense, uint64_t *denseOff, hipStream_t s)
+                    uint8_t *dense, size_t denseCap, uint64_t *denseOff, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, framedLen, nBlocks, denseOff);
     if (nBlocks > 0)
         hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)nBlocks), dim3(256), 0, s, slots, slotStride,
-                           framedLen, denseOff, dense);
+                           framedLen, denseOff, dense, (uint64_t)denseCap);
 }
 
 __global__ __launch_bounds__(256) void k_interleave(const uint8_t *local, const uint64_t *localOff, int rank,
@@ -349,31 +349,4 @@ void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
     if (a.nBlocks <= 0) return;
     const int ns = a.streamFirst ? a.nStreams : 1;
     if (ns > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)ns), dim3(64), 0, s, a);
-}
-
-// Two-wave lane-parallel decoder (decode_par2.hpp): one 128-thread workgroup per block,
-// wave 0 parses batch b+1 while wave 1 copies batch b.
-__global__ __launch_bounds__(128, P2_WAVES) void k_decode_par2(DecodeArgs a)
-{
-    __shared__ Par2Lds lds;
-    const int blk = (int)blockIdx.x;
-    const int role = uni((int)(threadIdx.x >> 6));
-    const uint8_t *data = nullptr;
-    int compLen = 0, cap = 0;
-    int r = read_block_header(a, blk, data, compLen, cap);
-    if (r == 0) {
-        uint8_t *dst = a.out + a.outOff[blk];
-        if (cap < 128 || compLen < 64) {
-            if (role == 1) r = decode_block_seq(data, compLen, dst, cap, nullptr, 0, a.framed, a.framed + a.framedLen);
-        } else {
-            r = decode_block_par2(role, data, compLen, dst, cap, a.framed, a.framed + a.framedLen, lds);
-        }
-    }
-    if (role == 1 && lane_id() == 0) a.result[blk] = r;
-}
-
-void launch_decode_par2(const DecodeArgs &a, hipStream_t s)
-{
-    if (a.nBlocks <= 0) return;
-    hipLaunchKernelGGL(k_decode_par2, dim3((unsigned)a.nBlocks), dim3(128), 0, s, a);
 }

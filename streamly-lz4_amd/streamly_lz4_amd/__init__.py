@@ -241,19 +241,24 @@ class Engine:
         self.ctx = C.c_void_p(lib.slz4_engine_ctx(self._h))
         self.device = device
         # The engine creates a non-blocking stream of its own.  The tensors this binding is handed are produced
-        # and consumed by torch on torch's current stream, so the binding launches there: a `torch.zeros(...)`
-        # followed by a decode into that tensor is then ordered without an explicit synchronisation.
-        self._on_torch_stream = False
+        # and consumed by torch on torch's CURRENT stream, so every device-API call launches there: the stream is
+        # re-read on each call (it changes under `with torch.cuda.stream(s):`), and a `torch.zeros(...)` followed
+        # by a decode into that tensor is ordered without an explicit synchronisation.  use_stream() pins the
+        # engine to one stream instead.
+        self._pinned = False
+        self._cur_stream = None
         self._follow_torch()
 
     def _follow_torch(self):
-        """Launch on torch's current stream once torch is in the process (it may be imported after the engine)."""
-        if self._on_torch_stream:
+        """Launch on torch's current stream for this device (torch may be imported after the engine)."""
+        if self._pinned:
             return
         torch = sys.modules.get("torch")
         if torch is not None and torch.cuda.is_available():
-            self.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
-            self._on_torch_stream = True
+            s = torch.cuda.current_stream(self.device).cuda_stream
+            if s != self._cur_stream:
+                _check(lib.mi355lz4_set_stream(self.ctx, C.c_void_p(s)), "set_stream")
+                self._cur_stream = s
 
     def close(self):
         if self._h:
@@ -273,7 +278,10 @@ class Engine:
         _check(lib.mi355lz4_set_decoder(self.ctx, int(variant)), "set_decoder")
 
     def use_stream(self, hip_stream):
+        """Pin the engine to one caller-owned hipStream_t (stops following torch's current stream)."""
         _check(lib.mi355lz4_set_stream(self.ctx, C.c_void_p(hip_stream)), "set_stream")
+        self._pinned = True
+        self._cur_stream = hip_stream
 
     def synchronize(self):
         _check(lib.mi355lz4_synchronize(self.ctx), "synchronize")

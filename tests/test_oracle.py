@@ -110,3 +110,21 @@ def test_vs_reference_decode_fuzz(oracle, reference):
                 a = oracle.decompress_block(payload, cap, dct)
                 b = reference.decompress_block(payload, cap, dct)
                 assert a == b, (it, len(payload), cap, dct is not None, a[0], b[0])
+
+
+def _huge_length_cases():
+    """Blocks whose literal / match length fields are multi-megabyte runs of 0xFF: the lengths reach
+    2^31 and beyond (cbits/lz4.c:1811-1818, 1854-1858, 2064-2065 compare them as size_t)."""
+    run = 8_600_000                                     # 255 * run > 2^31
+    lit = b"\xf0" + b"\xff" * run + b"\x07" + b"abc"    # literal length overflowing int
+    mat = b"\x1f" + b"x" + b"\x01\x00" + b"\xff" * run + b"\x03" + b"\x50hello"
+    mat_dict = b"\x1f" + b"x" + b"\x05\x00" + b"\xff" * run + b"\x03" + b"\x50hello"
+    return [("lit", lit, 4096), ("lit_bigcap", lit, 1 << 20), ("match", mat, 4096), ("match_cap64", mat, 40),
+            ("match_far", mat_dict, 1 << 16)]
+
+
+def test_huge_length_fields_vs_reference(oracle, reference):
+    for name, payload, cap in _huge_length_cases():
+        assert oracle.decompress_block(payload, cap) == reference.decompress_block(payload, cap), name
+        d = bytes(range(256)) * 16
+        assert oracle.decompress_block(payload, cap, d) == reference.decompress_block(payload, cap, d), name

@@ -27,7 +27,7 @@ def split_blocks(fr, meta=8):
 # --------------------------------------------------------------------------------------------
 # decode: bit-exact vs oracle / golden
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", [1, 2])
 @pytest.mark.parametrize("kind", ["lzsynth", "text", "random"])
 def test_decode_matches_oracle(engine, oracle, kind, decoder):
     engine.set_decoder(decoder)
@@ -67,7 +67,7 @@ def test_decode_linked_fixture(engine, linked_golden):
     assert blen == [linked_golden["block_len"]] * 4 and sha(out) == linked_golden["raw_sha256"]
 
 
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", [1, 2])
 def test_decode_malformed_codes(engine, golden, decoder):
     """Negative codes -(ip-src)-1 (cbits/lz4.c:2163) equal the reference's, for both decoder kernels."""
     engine.set_decoder(decoder)
@@ -85,7 +85,7 @@ def test_decode_malformed_codes(engine, golden, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", [1, 2])
 def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
     """Mutated / truncated blocks, batched: every status and every decoded byte equals the oracle's."""
     engine.set_decoder(decoder)
@@ -118,6 +118,24 @@ def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
                 assert blen == [want_code], (len(p), cap, blen, want_code)
                 if want_code >= 0:
                     assert out == want
+    finally:
+        engine.set_decoder(0)
+
+
+@pytest.mark.parametrize("decoder", [1, 2])
+def test_decode_huge_length_fields(engine, oracle, decoder):
+    """Length fields that are multi-megabyte runs of 0xFF (lengths >= 2^31): same code as the oracle, and
+    nothing is written outside the block's output (cbits/lz4.c:1811-1818, 1854-1858, 2064-2065)."""
+    from test_oracle import _huge_length_cases
+    engine.set_decoder(decoder)
+    try:
+        for name, payload, cap in _huge_length_cases():
+            fr = len(payload).to_bytes(4, "little") + cap.to_bytes(4, "little") + payload
+            want_code, want = oracle.decompress_block(payload, cap)
+            out, blen = engine.decompress_batch(fr, raise_on_block_error=False)
+            assert blen == [want_code], (name, blen, want_code)
+            if want_code >= 0:
+                assert out == want
     finally:
         engine.set_decoder(0)
 
@@ -172,7 +190,7 @@ def test_encode_roundtrips_through_oracle(engine, oracle, kind):
 def test_encode_size_vs_reference(engine, oracle):
     """Compressed size is reported against the reference's _continue path at the same acceleration
     (north star); it must stay within a few percent on the benchmark inputs."""
-    for kind, tol in (("lzsynth", 1.06), ("text", 1.06), ("random", 1.001)):
+    for kind, tol in (("lzsynth", 1.04), ("text", 1.06), ("random", 1.001)):
         for bl in (65536, 262144):
             for accel in (1, 5):
                 n = 8
