@@ -24,8 +24,29 @@ $(LIB): $(SRCS) $(HDRS)
 oracle:
 	$(MAKE) -C oracle
 
+# Host-side sanitizer builds (CPU only; GPU ASan is not available on this pool): api.cpp + host_stream.cpp
+# compiled by g++ against the HIP host API, kernel launchers stubbed, driven by tests/native/host_san_test.cpp.
+SAN_SRCS := $(CSRC)/api.cpp $(CSRC)/host_stream.cpp tests/native/san_stubs.cpp tests/native/host_san_test.cpp
+SAN_FLAGS := -std=c++17 -O1 -g -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wall -Wno-unused-function -Wno-unused-result
+SAN_LIBS := -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread
+
+build/san/host_asan: $(SAN_SRCS) $(HDRS)
+	@mkdir -p build/san
+	g++ $(SAN_FLAGS) -fsanitize=address,undefined -fno-sanitize-recover=undefined -o $@ $(SAN_SRCS) $(SAN_LIBS)
+
+build/san/host_tsan: $(SAN_SRCS) $(HDRS)
+	@mkdir -p build/san
+	g++ $(SAN_FLAGS) -fsanitize=thread -o $@ $(SAN_SRCS) $(SAN_LIBS)
+
+asan: build/san/host_asan
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 LSAN_OPTIONS=suppressions=tests/native/lsan.supp ./build/san/host_asan
+
+tsan: build/san/host_tsan
+	TSAN_OPTIONS=halt_on_error=1 ./build/san/host_tsan
+
 clean:
+	rm -rf build/san
 	rm -f $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle clean asan tsan

@@ -1,55 +1,81 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X LZ4 block engine.
 
-    python bench.py --gpus N --steps K --warmup W [--workload decompress|compress|roundtrip|random256k]
+    python bench.py --gpus N --steps K --warmup W [--workload decompress|compress|roundtrip|random256k|text]
 
-One "step" = one pass of the hot path over one batch of synthetic input resident in HBM.
-Default workload (N=1) is BASELINE.json configs[1]: decompress-only, 64 KiB blocks, 4 GiB
-lzsynth(16, 2048) stream of independent blocks (compressed by this engine during setup).  For N>1
-(one process per GPU under torch.distributed.run, RCCL) block k of the global stream lives on rank
-k % N (per-block round-robin); every rank processes 4 GiB (weak scaling) with no data-path
-collective.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of input resident in HBM.  Default workload (N=1)
+is BASELINE.json configs[1]: decompress-only, 64 KiB blocks, 4 GiB lzsynth(16, 2048) stream of
+independent blocks (compressed by this engine during setup).  For N>1 (one process per GPU under
+torch.distributed.run, RCCL) block k of the global stream lives on rank k % N (per-block round-robin);
+every rank processes 4 GiB (weak scaling) with no data-path collective.  Rank 0 prints ONE JSON line.
 
-`value` is whole-job GB/s of UNCOMPRESSED bytes over the wall-clock of the K timed steps (max over
-ranks).  `roofline` prices the dominant kernel: algorithmic bytes (U + C) per launch /
-its average launch duration, measured live with HIP events on the engine's own stream, against the
-8 TB/s HBM peak.  `cpu_baseline` times the reference codec (oracle/_ref, kind "reference"; or the
-oracle port) on ONE host core on a bounded sample of the same input -- context, not the target.
+`value` is whole-job GB/s of UNCOMPRESSED bytes over the wall-clock of the K timed steps (max over ranks).
+`roofline` prices the dominant kernel of the timed phase: algorithmic bytes (U + C) per
+launch / its average launch duration, measured live with HIP events on the stream the kernels are launched
+on, against the 8 TB/s HBM peak.  The metric's name says compress+decompress, so the same line also carries
+`roundtrip` (compress + compact + decompress of the same data, timed after the K steps) and `compress`
+(the encoder's own roofline block).  `cpu_baseline` times the reference codec (oracle/_ref, kind
+"reference"; or the oracle port) on ONE host core on a bounded sample of the same input -- context, not
+the target; its `ratio` is the reference's compressed size for the same data.
+
+N>1 also runs the RCCL ordered gather of the framed output once (untimed by `value`), decodes the gathered
+stream on the root and compares it with the generator's global stream, and reports compute-only and
+compute+gather rates.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "streamly-lz4_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
     # name: (kind, block_len, n_blocks_per_gpu, accel, timed phase)
     "decompress": ("lzsynth", 65536, 65536, 1, "decompress"),   # BASELINE configs[1]
-    "compress": ("lzsynth", 65536, 65536, 1, "compress"),       # configs[2] shape on lzsynth (Canterbury absent offline)
+    "compress": ("lzsynth", 65536, 65536, 1, "compress"),       # configs[2] shape; Canterbury "large" when present
     "roundtrip": ("lzsynth", 65536, 65536, 1, "roundtrip"),     # configs[3] per-GPU share
     "random256k": ("random", 262144, 16384, 400, "roundtrip"),  # configs[4] per-GPU share
     "text": ("text", 65536, 65536, 1, "decompress"),
 }
 
 
+def canterbury_large(n_bytes):
+    """configs[2] input: bible.txt, E.coli, world192.txt of the Canterbury "large" corpus, each cycled like
+    the reference's benchmark cycles its files (benchmark/Main.hs:80-84), laid end to end.  None if absent."""
+    try:
+        import corpus
+    except Exception:
+        return None, None
+    paths = [corpus.find(r) for r in ("large/bible.txt", "large/E.coli", "large/world192.txt")]
+    if not all(paths):
+        return None, None
+    share = n_bytes // len(paths) // 65536 * 65536
+    parts = [corpus.cycled(p, share) for p in paths[:-1]]
+    parts.append(corpus.cycled(paths[-1], n_bytes - share * (len(paths) - 1)))
+    return b"".join(parts), "Canterbury large (bible.txt, E.coli, world192.txt cycled)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="decompress", choices=sorted(WORKLOADS))
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default: workload's)")
     ap.add_argument("--decoder", type=int, default=0, help="0 auto, 1 sequence-at-a-time, 2 lane-parallel")
+    ap.add_argument("--linked", action="store_true", help="decode with linked = 1 (reference stream semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the multi-threaded best-case CPU figure")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0)
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL ordered gather of the framed output (N>1)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL ordered gather + its verification")
+    ap.add_argument("--no-extra", action="store_true", help="skip the round-trip / compress figures measured after the timed steps")
     args = ap.parse_args()
 
     import torch
@@ -84,10 +110,19 @@ def main():
     eng = S.Engine(dev_index)
     eng.set_decoder(args.decoder)
 
-    # ---- setup (untimed): generate this rank's blocks on the device, compress, compact ----
+    # ---- setup (untimed): this rank's blocks on the device, compressed and compacted ----
     U = NB * BL
+    data_name = "synthetic"
     src = torch.empty(U, dtype=torch.uint8, device=dev)
-    eng.generate(kind, src, BL, NB, first_block=rank, block_step=world)      # block k -> rank k % N
+    corpus_bytes = None
+    if args.workload == "compress" and world == 1:
+        corpus_bytes, cname = canterbury_large(U)
+    if corpus_bytes is not None:
+        import numpy as np
+        src.copy_(torch.from_numpy(np.frombuffer(corpus_bytes, dtype=np.uint8).copy()))
+        kind, data_name = "canterbury-large", cname
+    else:
+        eng.generate(kind, src, BL, NB, first_block=rank, block_step=world)      # block k -> rank k % N
     stride = S.slot_stride(BL, 8)
     slots = torch.empty(NB * stride, dtype=torch.uint8, device=dev)
     flen = torch.empty(NB, dtype=torch.int32, device=dev)
@@ -103,20 +138,11 @@ def main():
         eng.compact_device(slots, stride, flen, NB, dense, NB * stride, doff)
 
     def do_decompress():
-        eng.decompress_batch_device(dense, Cbytes, doff, NB, out, ooff, res)
+        eng.decompress_batch_device(dense, Cbytes, doff, NB, out, ooff, res, linked=args.linked)
 
     Cbytes = NB * stride
     do_compress()                                                             # first touch
     eng.synchronize()
-    se = [S.Event() for _ in range(3)]
-    eng.record(se[0])
-    eng.compress_batch_device(src, NB, BL, slots, stride, flen, accel=accel)
-    eng.record(se[1])
-    eng.compact_device(slots, stride, flen, NB, dense, NB * stride, doff)
-    eng.record(se[2])
-    eng.synchronize()
-    setup_compress_ms = eng.elapsed_ms(se[0], se[1])                          # reported as context (untimed phase)
-    setup_compact_ms = eng.elapsed_ms(se[1], se[2])
     Cbytes = int(doff[-1].item())                                             # compressed bytes incl. 8-byte headers
     do_decompress()
     eng.synchronize()
@@ -126,23 +152,23 @@ def main():
     ev = [S.Event() for _ in range(4)]
     kern_ms = {"compress": [], "compact": [], "decompress": []}
 
-    def step():
-        if phase in ("compress", "roundtrip"):
+    def step(ph):
+        if ph in ("compress", "roundtrip"):
             eng.record(ev[0])
             eng.compress_batch_device(src, NB, BL, slots, stride, flen, accel=accel)
             eng.record(ev[1])
             eng.compact_device(slots, stride, flen, NB, dense, NB * stride, doff)
             eng.record(ev[2])
-        if phase in ("decompress", "roundtrip"):
-            if phase == "decompress":
+        if ph in ("decompress", "roundtrip"):
+            if ph == "decompress":
                 eng.record(ev[2])
             do_decompress()
             eng.record(ev[3])
         eng.synchronize()
-        if phase in ("compress", "roundtrip"):
+        if ph in ("compress", "roundtrip"):
             kern_ms["compress"].append(eng.elapsed_ms(ev[0], ev[1]))
             kern_ms["compact"].append(eng.elapsed_ms(ev[1], ev[2]))
-        if phase in ("decompress", "roundtrip"):
+        if ph in ("decompress", "roundtrip"):
             kern_ms["decompress"].append(eng.elapsed_ms(ev[2], ev[3]))
 
     def barrier():
@@ -151,13 +177,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step(phase)
     for k in kern_ms:
         kern_ms[k].clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(phase)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -166,17 +192,63 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = world * U / (elapsed / max(args.steps, 1)) / 1e9
+    timed_ms = {k: (sum(v) / len(v) if v else None) for k, v in kern_ms.items()}
 
-    # ---- optional: ordered RCCL gather of the framed output to rank 0 (reported separately) ----
-    gather_ms = None
-    if args.gather and dist is not None:
+    # ---- after the timed steps: the other half of the metric's name (same data, same build) ----
+    extra = None
+    if not args.no_extra:
+        for k in kern_ms:
+            kern_ms[k].clear()
+        barrier()
+        r0 = time.perf_counter()
+        n_rt = 3
+        for _ in range(n_rt):
+            step("roundtrip")
+        barrier()
+        rt_s = (time.perf_counter() - r0) / n_rt
+        if dist is not None:
+            tt = torch.tensor([rt_s], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            rt_s = float(tt.item())
+        cm = sum(kern_ms["compress"]) / n_rt
+        km = sum(kern_ms["compact"]) / n_rt
+        dm = sum(kern_ms["decompress"]) / n_rt
+        extra = {"roundtrip_GBps": round(world * U / rt_s / 1e9, 2), "roundtrip_ms_per_step": round(rt_s * 1e3, 4),
+                 "kernels_ms": {"compress": round(cm, 4), "compact": round(km, 4), "decompress": round(dm, 4)},
+                 "compress": {"GBps": round(U / cm / 1e6, 2), "achieved": round((U + Cbytes) / cm / 1e6, 2),
+                              "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round((U + Cbytes) / cm / 1e6 / HBM_PEAK_GBPS, 5), "avg_launch_ms": round(cm, 4)},
+                 "decompress": {"GBps": round(U / dm / 1e6, 2), "frac": round((U + Cbytes) / dm / 1e6 / HBM_PEAK_GBPS, 5)}}
+
+    # ---- N>1: ordered RCCL gather of the framed output to rank 0, verified, reported separately ----
+    gather = None
+    if dist is not None and not args.no_gather:
         from streamly_lz4_amd.gather import gather_ordered
+        do_compress()
+        eng.synchronize()
         fl = flen.clone()
         barrier()
         g0 = time.perf_counter()
         gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)
         barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        gather_s = time.perf_counter() - g0
+        gather = {"ms": round(gather_s * 1e3, 3)}
+        if rank == 0:
+            # the gathered stream must decode to the generator's GLOBAL stream (block k = generator block k)
+            nG = NB * world
+            gsrc = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
+            eng.generate(kind, gsrc, BL, nG, first_block=0, block_step=1)
+            gout = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
+            gres = torch.empty(nG, dtype=torch.int32, device=dev)
+            gooff = torch.arange(nG + 1, dtype=torch.int64, device=dev) * BL
+            eng.decompress_batch_device(gathered, int(goff[-1].item()), goff, nG, gout, gooff, gres)
+            eng.synchronize()
+            ok = bool((gres == BL).all().item()) and torch.equal(gout, gsrc)
+            gather["verified"] = ok
+            gather["bytes"] = int(goff[-1].item())
+            if not ok:
+                sys.exit("bench.py: the gathered stream does not decode to the generator's global stream")
+            del gsrc, gout, gres, gooff
         del gathered
 
     if rank != 0:
@@ -184,15 +256,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel ----
+    # ---- roofline of the dominant kernel of the timed phase ----
     dom = "decompress" if phase in ("decompress", "roundtrip") else "compress"
-    avg_ms = sum(kern_ms[dom]) / max(len(kern_ms[dom]), 1)
+    avg_ms = timed_ms[dom] or 0.0
     achieved = (U + Cbytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("%s:%s" % (args.workload, dom))
+            tj = json.load(open(tpath))
+            traffic = tj.get("%s:%s" % (args.workload, dom))
+            traffic_src = "profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of %s)" % tj.get("_commit", "an earlier commit")
         except Exception:
             traffic = None
     # what a plain device-to-device copy of the same U bytes reaches on this box (read + write)
@@ -205,7 +279,7 @@ def main():
     except Exception:
         copy_GBps = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": U + Cbytes, "avg_launch_ms": round(avg_ms, 4),
                 "device_copy_GBps": copy_GBps}
 
@@ -219,12 +293,15 @@ def main():
         r = orc.cpu_baseline(blocks, accel=accel)
         cpu_dec = r["raw_bytes"] / r["decomp_s"] / 1e9
         cpu_cmp = r["raw_bytes"] / r["comp_s"] / 1e9
+        gpu_sample_bytes = int(doff[ns].item())
         cpu = {"value": round(cpu_dec if dom == "decompress" else cpu_cmp, 3), "unit": "GB/s", "cores": 1,
                "kind": r["kind"],
                "sample": "first %d blocks (%d MiB) of the same %s stream, reference call sequence (one linked context), best of 3"
                          % (ns, ns * BL >> 20, kind),
                "decompress_GBps": round(cpu_dec, 3), "compress_GBps": round(cpu_cmp, 3),
-               "ratio": round(r["raw_bytes"] / (r["comp_bytes"] + 8 * ns), 4)}
+               "ratio": round(r["raw_bytes"] / (r["comp_bytes"] + 8 * ns), 4),
+               "gpu_ratio_same_sample": round(ns * BL / gpu_sample_bytes, 4),
+               "gpu_size_vs_reference": round(gpu_sample_bytes / (r["comp_bytes"] + 8 * ns), 4)}
         if not args.no_cpu_all_cores:
             # best-case CPU, NOT reference behaviour (its API is one serial stream): one independent
             # linked context per host thread over contiguous block ranges of the same sample
@@ -237,19 +314,24 @@ def main():
         "metric": "GB/s uncompressed (compress+decompress), 64 KiB blocks, 1/2/4/8 GPU",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "u8", "data": data_name,
         "config": {"workload": "%s: %s, %d KiB blocks, %d blocks (%.2f GiB) per GPU, %s, accel %d, independent blocks, "
-                               "round-robin block->GPU" % (args.workload, phase, BL >> 10, NB, U / 2 ** 30, kind, accel),
+                               "round-robin block->GPU%s" % (args.workload, phase, BL >> 10, NB, U / 2 ** 30, kind, accel,
+                                                             ", linked=1" if args.linked else ""),
                    "block_len": BL, "blocks_per_gpu": NB, "ratio": round(U / Cbytes, 4), "decoder": args.decoder},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "kernels_ms": {k: round(sum(v) / len(v), 4) for k, v in kern_ms.items() if v},
-        # context from the untimed setup pass over the same data (per GPU): the other half of the metric's name
-        "setup": {"compress_GBps": round(U / setup_compress_ms / 1e6, 2), "compact_ms": round(setup_compact_ms, 4),
-                  "compress_roofline_frac": round((U + Cbytes) / setup_compress_ms / 1e6 / HBM_PEAK_GBPS, 5)},
+        "kernels_ms": {k: round(v, 4) for k, v in timed_ms.items() if v},
     }
-    if gather_ms is not None:
-        line["gather_ms"] = round(gather_ms, 3)
+    if extra is not None:
+        line["roundtrip"] = extra
+    if gather is not None:
+        # compute-only is `value`; compute+gather adds one ordered gather per compress pass
+        cm = (extra or {}).get("kernels_ms", {}).get("compress")
+        if cm:
+            gather["compress_only_GBps"] = round(world * U / cm / 1e6, 2)
+            gather["compress_plus_gather_GBps"] = round(world * U / (cm + gather["ms"]) / 1e6, 2)
+        line["gather"] = gather
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

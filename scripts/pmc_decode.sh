@@ -2,6 +2,7 @@
 # Development aid: instruction-mix / busy counters of the decode kernel (one --pmc pass per group).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 KIND=${1:-lzsynth}
+KPAT=${2:-k_decode_par}      # kernel-name substring; DEC_VARIANT selects the decoder variant
 OUT=$R/gpurun_out/pmc_dec_$KIND
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -14,12 +15,12 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/scripts/prof_decode.py" $KIND 32768 2 > "$OUT/g$i.log" 2>&1
 done
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$KPAT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_decode_par" in row["Kernel_Name"]:
+        if sys.argv[2] in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]

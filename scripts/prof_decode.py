@@ -8,6 +8,7 @@ NB = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 BL = 65536
 dev = torch.device("cuda:0"); eng = S.Engine(0)
+eng.set_decoder(int(os.environ.get("DEC_VARIANT", "0")))
 src = torch.empty(NB * BL, dtype=torch.uint8, device=dev); eng.generate(kind, src, BL, NB)
 stride = S.slot_stride(BL, 8)
 slots = torch.empty(NB * stride, dtype=torch.uint8, device=dev); flen = torch.empty(NB, dtype=torch.int32, device=dev)

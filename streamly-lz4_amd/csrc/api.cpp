@@ -148,6 +148,7 @@ struct mi355lz4_ctx {
     int decoder = 0;
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
+    DevBuf tok, tokOff, tokCnt, tokSizes;   // token lists of the list-driven decoder
     DevBuf pinIn, pinOut;   // pinned host staging
     unsigned long long *stats = nullptr;   // diagnostics: device counters of the lane-parallel decoder (off by default)
 };
@@ -240,6 +241,15 @@ static bool device_is_gfx950(int dev)
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
+// Diagnostic hook (not part of the public header): one copy through the staging copy pool, so that the
+// sanitizer driver (tests/native/host_san_test.cpp) can exercise the pool without a device.
+extern "C" int mi355lz4_debug_host_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    if (n && (!dst || !src)) return fail(MI355LZ4_E_ARG, "debug_host_copy: null pointer");
+    copy_pool().copy(dst, src, n);
+    return MI355LZ4_OK;
+}
+
 extern "C" int mi355lz4_version(void) { return MI355LZ4_VERSION; }
 extern "C" const char *mi355lz4_last_error(void) { return g_err; }
 
@@ -279,7 +289,8 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch})
+    for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
+                      &c->tok, &c->tokOff, &c->tokCnt, &c->tokSizes})
         dev_release(*b);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
@@ -306,7 +317,7 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -405,8 +416,23 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
     a.streamFirst = streamFirst; a.nStreams = nStreams;
+    a.tok = nullptr; a.tokOff = nullptr; a.tokCnt = nullptr; a.tokSizes = nullptr; a.tokCap = 0;
+    if (c->decoder == 3) {
+        // every sequence takes >= 3 compressed bytes: framedLen / 3 entries (+2 per block) hold every list of
+        // disjoint blocks; lists that would not fit (overlapping blockOff) stay empty and decode sequentially
+        const uint64_t entries = framedLen / 3 + 2ull * (uint64_t)nBlocks + 64;
+        int r = dev_reserve(c->tok, entries * sizeof(uint16_t));
+        if (!r) r = dev_reserve(c->tokOff, ((size_t)nBlocks + 1) * sizeof(uint64_t));
+        if (!r) r = dev_reserve(c->tokCnt, (size_t)nBlocks * sizeof(int32_t));
+        if (!r) r = dev_reserve(c->tokSizes, (size_t)nBlocks * sizeof(int32_t));
+        if (r) return r;
+        a.tok = (uint16_t *)c->tok.p; a.tokOff = (uint64_t *)c->tokOff.p; a.tokCnt = (int32_t *)c->tokCnt.p;
+        a.tokSizes = (int32_t *)c->tokSizes.p; a.tokCap = entries;
+    }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
+    else if (c->decoder == 3)
+        launch_decode_tok(a, c->stats, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
     if (linked) launch_decode_fixup_linked(a, c->stream);

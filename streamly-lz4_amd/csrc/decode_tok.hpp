@@ -1,0 +1,445 @@
+// decode_tok.hpp -- lane-parallel LZ4 block decoder driven by a token list: one wavefront per block,
+// 64 sequences per iteration, token positions supplied by the parse kernel (tok_parse.hpp).
+//
+// Same contract and same results as decode_seq.hpp (reference
+// LZ4_decompress_generic, cbits/lz4.c:1737-2165): this file only changes HOW the
+// interior of a block is decoded.  A sequence-at-a-time decoder is bound by the
+// serial token chain (cbits/lz4.c:1801-1854: sequence i+1 starts where sequence i
+// ends) at ~30-50 issue slots and two dependent memory round trips per ~27-byte
+// sequence.  Here one iteration handles a BATCH of sequences:
+//
+//   1. window     1 KiB of the compressed stream is staged in LDS (16 B / lane;
+//                 the next window is prefetched into registers while this one is used).
+//   2. speculate  every lane parses 8 candidate token positions (512 candidates)
+//                 from registers: where would the next token be if one started here?
+//   3. chain      pointer jumping over that successor table: after round k lanes
+//                 0..2^k-1 hold the first 2^k real token positions.  Three rounds give
+//                 jump^8 for every node and lanes 0..7; then lanes 8g..8g+7 follow the
+//                 real chain from lanes 8(g-1)..8g-1 (one 8-lane gather per group), so
+//                 sequence r ends up on lane r.
+//   4. decode     lane r decodes sequence r (lengths, offset); a DPP wave scan of the
+//                 output lengths gives every sequence its output position.
+//   5. far        matches whose source was already flushed to global memory are
+//                 fetched in one batched pass (no dependence on this batch).
+//   6. literals   lane-per-sequence copy, LDS window -> LDS output ring.
+//   7. matches    dependency rounds: a match is ready when every sequence its
+//                 source overlaps is complete (64-bit ballot mask); ready lanes copy
+//                 two chunks (2 x 16 / 8 / 4 bytes) per step inside the LDS ring, all
+//                 reads of a step before its first write.
+//   8. flush      completed output leaves the ring with aligned 16-byte stores.
+//
+// Only "plain interior" sequences are handled here: single-byte length
+// extensions, offset != 0, source inside the block, far enough from both ends
+// that the reference would still be in its fast loop and could not fail.  On
+// anything else the block position is handed to decode_seq_run() for ONE
+// sequence (or for the rest of the block near its end), which is also what
+// produces the reference's exact error codes.
+#pragma once
+
+#include "decode_par.hpp"
+
+namespace lz4dev {
+
+struct __attribute__((aligned(16))) TokLds {
+    uint8_t win[PAR_WIN + 32];
+    uint8_t ring[PAR_RING + 32];
+};
+
+template <bool STATS, bool DICT>
+__device__ int decode_block_tok(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict,
+                                uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, TokLds &L,
+                                const uint16_t *tok, int nTok, unsigned long long *stats)
+{
+    uint32_t sc[PS_COUNT];                 // wave-uniform (kept in scalar registers)
+    uint32_t tmark = 0;
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < PS_COUNT; i++) sc[i] = 0;
+        tmark = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());
+    }
+    auto lap = [&](int which) {
+        if (STATS) {
+            const uint32_t now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime());
+            sc[which] += now - tmark;
+            tmark = now;
+        }
+    };
+    auto publish = [&]() {
+        if (STATS && lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], (unsigned long long)sc[i]);
+        }
+    };
+    if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+    // external dictionary (linked streams, cbits/lz4.c:2347-2355): a match that lies ENTIRELY in the
+    // previous block's output is a far match with another base pointer; one that straddles the seam
+    // (:1883-1911) is left to the sequential decoder
+    if (!DICT) { dict = nullptr; dictLen = 0; }
+    const uint8_t *dictEnd = DICT ? dict + dictLen : dst;
+    const int dictLo = DICT ? -(int)min(dictLen, 65535u) : 0;
+
+    int lane = lane_id();
+    const int iend = srcLen;
+    const uint32_t A = (uint32_t)((uintptr_t)dst & 15);   // ring index of output position p is p - ringBase + A
+    int ip = 0, op = 0;
+    int ringBase = 0;       // multiple of 16
+    int flushed = 0;        // output positions < flushed are in global memory
+    SeqState st;
+
+    // 16 bytes of the compressed stream for this lane's slot of the window that starts at `base`
+    auto fetch_window = [&](uintptr_t base) -> uint4 {
+        const uint8_t *q = (const uint8_t *)(base + 16u * (uint32_t)lane);
+        if (q >= bufLo && q + 16 <= bufHi) {
+            const par_v4 v = *as_global((const par_v4 *)q);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; k++)
+            if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)as_global(q)[k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+
+    // ring -> global for positions [flushed, upto); 16-byte aligned stores in the body.
+    auto flush = [&](int upto, bool final) {
+        wave_fence();
+        int f = flushed;
+        const int mis = (int)((A + (uint32_t)f) & 15u);
+        if (mis) {
+            const int head = 16 - mis;
+            if (upto - f >= head) {
+                if (lane < head) dst[f + lane] = L.ring[f - ringBase + (int)A + lane];
+                f += head;
+            } else if (!final) {
+                return;
+            }
+        }
+        if (((A + (uint32_t)f) & 15u) == 0) {
+            const int n16 = (upto - f) >> 4;
+            for (int c = lane; c < n16; c += LZ4_WAVE) {
+                const uint4 v = *(const uint4 *)&L.ring[f - ringBase + (int)A + 16 * c];
+                *(uint4 *)(dst + f + 16 * c) = v;
+            }
+            f += n16 << 4;
+        }
+        if (final) {
+            for (int x = f + lane; x < upto; x += LZ4_WAVE) dst[x] = L.ring[x - ringBase + (int)A];
+            f = upto;
+        }
+        flushed = f;
+        wave_fence();
+    };
+
+    uintptr_t wbase = (uintptr_t)src & ~(uintptr_t)15;     // window base whose data is in `wnext`
+    uint4 wnext = fetch_window(wbase);
+    bool winStale = true;                                  // L.win does not hold the window at wbase yet
+    int seqIdx = 0;                                        // next entry of the token list
+    // this lane's entry of the next batch: compressed length of sequence seqIdx + lane
+    auto fetch_tok = [&](int idx) -> uint32_t {
+        return (idx + lane < nTok) ? (uint32_t)as_global(tok)[idx + lane] : 0u;
+    };
+    uint32_t dcur = fetch_tok(0);
+
+    for (;;) {
+        // ================= hot loop: batches of plain interior sequences =================
+        while (iend - ip >= 64 && cap - op >= 128 && seqIdx < nTok) {
+            lap(PS_T_FLUSH);
+
+            // ---------------- 1. window ----------------
+            const uint8_t *gp = src + ip;
+            const uintptr_t abase = (uintptr_t)gp & ~(uintptr_t)15;
+            const int wofs = (int)((uintptr_t)gp - abase);
+            const int ipW0 = ip - wofs;                    // block-relative position of window byte 0
+            const int iendW = iend - ipW0;                 // block end in window coordinates
+            const int inLim = min(iendW - 32, PAR_WIN);    // a plain sequence must end at or before this
+            // L.win already holds this window (stored at the end of the previous batch) unless this is
+            // the first batch or the one after a handover
+            if (abase != wbase) { wbase = abase; wnext = fetch_window(abase); winStale = true; }
+            if (winStale) {
+                *(uint4 *)&L.win[16 * lane] = wnext;
+                winStale = false;
+                wave_fence();
+            }
+            lap(PS_T_WINDOW);
+
+            // ---------------- 2./3. token positions: sequence seqIdx + r -> lane r ----------------
+            // the list holds the compressed length of every sequence; a wave scan places the tokens
+            const int dincl = par_scan_incl((int)dcur);
+            const uint32_t cpos = (uint32_t)(wofs + dincl - (int)dcur);           // token position in the window
+            lap(PS_T_CHAIN);
+
+            // ---------------- 4. decode own sequence, place it ----------------
+            const bool has = (seqIdx + lane < nTok) && cpos < (uint32_t)PAR_WIN;
+            const uint32_t cc = has ? cpos : 0u;
+            const uint32_t tb = lds_u32_any(L.win, cc);                          // token, next byte
+            const uint32_t t = tb & 0xffu, b1 = (tb >> 8) & 0xffu;
+            const bool is15 = (t >> 4) == 15u;
+            const uint32_t lit = is15 ? 15u + b1 : (t >> 4);
+            const uint32_t litStart = cc + 1u + (is15 ? 1u : 0u);
+            const uint32_t offPos = litStart + lit;                             // <= 511 + 272: inside the window
+            const uint32_t ob = lds_u32_any(L.win, offPos);                      // offset (2 bytes), match-length byte
+            const uint32_t off16 = ob & 0xffffu, b2 = (ob >> 16) & 0xffu;
+            const bool mlx = (t & 15u) == 15u;
+            const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
+            const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u);
+            bool ok = has && !(is15 && b1 == 255u) && !(mlx && b2 == 255u) && (int)nxt <= inLim && off16 != 0;
+            const int len = ok ? (int)(lit + ml) : 0;
+            const int incl = par_scan_incl(len);
+            const int outEnd = op + incl;
+            const int outStart = outEnd - len;
+            const int dpos = outStart + (int)lit;            // match destination
+            const int spos = dpos - (int)off16;              // match source
+            ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap &&
+                 ((spos >= 0 && (spos >= ringBase || spos + (int)ml <= flushed)) ||
+                  (DICT && spos >= dictLo && spos + (int)ml <= 0));
+            const uint64_t okm = __ballot(ok);
+            const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
+            lap(PS_T_DECODE);
+            if (STATS) { sc[PS_BATCHES]++; sc[PS_SEQS] += (unsigned)nseq; if (nseq == LZ4_WAVE) sc[PS_FULL]++; }
+            if (nseq == 0) break;                            // not a plain interior sequence: slow path below
+
+            const bool act = lane < nseq;
+            const uint32_t dnext = fetch_tok(seqIdx + nseq);
+            const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
+            const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
+            // prefetch the next window while this batch is copied (measured: issuing it here, before the
+            // far pass, beats issuing it after, although the far pass then also waits for it)
+            {
+                const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
+                wbase = nb;
+                wnext = fetch_window(nb);
+            }
+
+            const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
+            const bool nearSrc = spos >= ringBase;
+            const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
+            const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
+            const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups never read their own writes
+            const bool g16 = grp && ml >= 16;                       // ... as two 16-byte chunks
+            const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
+            const bool g4 = ml < 8 && off16 >= ml;                  // 4 <= ml < 8, no self-overlap: two 4-byte chunks
+            const bool fastc = g16 || g8 || g4;
+
+            // ---------------- dependency masks (independent of the copies below: issued first so that
+            // their cross-lane traffic overlaps the literal and far copies) ----------------
+            uint64_t need = 0;
+            {
+                // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
+                const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
+                const int xlo = max(spos, op), xhi = max(srcHi - 1, op);
+                int jlo = 0, jhi = 0;
+#pragma unroll
+                for (int stp = 32; stp >= 1; stp >>= 1) {
+                    const int c1 = jlo + stp, cb = jhi + stp;
+                    const int v1 = par_bperm(outStart, c1 & 63), v2 = par_bperm(outStart, cb & 63);
+                    if (c1 < nseq && v1 <= xlo) jlo = c1;
+                    if (cb < nseq && v2 <= xhi) jhi = cb;
+                }
+                if (act && nearSrc && srcHi > op && srcHi > spos) {
+                    const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
+                    need = upto & ~((1ull << jlo) - 1ull);
+                    need &= ~(1ull << lane);
+                }
+            }
+            // ---------------- 5. literals: window -> ring ----------------
+            {
+                const uint32_t sA = litStart;
+                const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
+                const uint32_t n = act ? lit : 0u;
+                if (n > 8) {                                    // rare (token nibble 15 or close to it)
+                    const uint32_t last = n - 8;
+                    for (uint32_t o = 0;; o += 8) {
+                        const uint32_t oo = min(o, last);
+                        *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
+                        if (o >= last) break;
+                    }
+                } else if (n > 0) {
+                    const uint64_t v = lds_u64_any(L.win, sA);  // aligned reads + funnel
+                    if (n + ml >= 8) {
+                        // one 8-byte store; the bytes past the literals fall into my own match area, which is
+                        // written afterwards (steps 6 and 7)
+                        *(par_u64u *)&L.ring[dA] = v;
+                    } else {
+                        uint64_t w = v;
+                        for (uint32_t q = 0; q < n; q++) { L.ring[dA + q] = (uint8_t)w; w >>= 8; }
+                    }
+                }
+            }
+            wave_fence();
+
+            // ---------------- 6. far matches: source already in global memory ----------------
+            const uint64_t farm = __ballot(act && !nearSrc);
+            if (farm) {
+                if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
+                const uint8_t *gsrc = (DICT && spos < 0) ? dictEnd + spos : dst + spos;
+                const bool mine = act && !nearSrc;
+                // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
+                // past the match is written.  Far sources never overlap their destination.
+                const uint32_t step = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
+                const uint32_t last = ml - step;
+                for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
+                    // every load of the pass is issued before the first store waits for one: a single
+                    // round trip to L2/HBM per 32 bytes, whatever mix of chunk sizes the lanes have
+                    par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+                    const bool on = mine && base < ml;
+                    const uint32_t o0 = (step == 16) ? min(base, last) : 0u;
+                    const uint32_t o1 = (step == 16) ? min(base + 16u, last) : last;
+                    if (on) {
+                        if (step == 16) {
+                            __builtin_memcpy(&v0, gsrc + o0, 16);
+                            __builtin_memcpy(&v1, gsrc + o1, 16);
+                        } else if (step == 8) {
+                            const uint64_t a = *(const par_u64u *)(gsrc), b = *(const par_u64u *)(gsrc + last);
+                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
+                            v1.x = (uint32_t)b; v1.y = (uint32_t)(b >> 32);
+                        } else {
+                            v0.x = *(const par_u32u *)(gsrc);
+                            v1.x = *(const par_u32u *)(gsrc + last);
+                        }
+                    }
+                    if (on) {
+                        if (step == 16) {
+                            *(par_v4u *)&L.ring[mdA + o0] = v0;
+                            *(par_v4u *)&L.ring[mdA + o1] = v1;
+                        } else if (step == 8) {
+                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
+                            *(par_u64u *)&L.ring[mdA + last] = ((uint64_t)v1.y << 32) | v1.x;
+                        } else {
+                            *(par_u32u *)&L.ring[mdA] = v0.x;
+                            *(par_u32u *)&L.ring[mdA + last] = v1.x;
+                        }
+                    }
+                }
+            }
+
+            // ---------------- 7. near matches: dependency rounds ----------------
+            lap(PS_T_NEED);
+            need &= ~farm;                                              // far matches are already in place
+            uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
+            bool pending = act && nearSrc;                              // my match still has to be copied
+            const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
+            while (~done) {
+                const bool mine = pending && ((need & ~done) == 0ull);
+                if (STATS) sc[PS_ROUNDS]++;
+                // lanes whose chunks never read their own writes: two chunks per step (2 x 16, 2 x 8 or 2 x 4
+                // bytes by class), every lane's reads issued before the first write, so that a round costs
+                // one LDS round trip per 32 bytes whatever mix of classes is ready
+                for (uint32_t base = 0; __ballot(mine && fastc && base < ml); base += 32) {
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    const bool on = mine && fastc && base < ml;
+                    const uint32_t cs = g16 ? 16u : (g8 ? 8u : 4u);
+                    const uint32_t lastc = ml - cs;
+                    const uint32_t o0 = g16 ? min(base, lastc) : 0u;
+                    const uint32_t o1 = g16 ? min(base + 16u, lastc) : lastc;
+                    par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+                    if (on) {
+                        if (g16) {
+                            v0 = *(const par_v4u *)&L.ring[msA + o0];
+                            v1 = *(const par_v4u *)&L.ring[msA + o1];
+                        } else if (g8) {
+                            const uint64_t a = *(const par_u64u *)&L.ring[msA], c = *(const par_u64u *)&L.ring[msA + o1];
+                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
+                            v1.x = (uint32_t)c; v1.y = (uint32_t)(c >> 32);
+                        } else {
+                            v0.x = *(const par_u32u *)&L.ring[msA];
+                            v1.x = *(const par_u32u *)&L.ring[msA + o1];
+                        }
+                    }
+                    if (on) {
+                        if (g16) {
+                            *(par_v4u *)&L.ring[mdA + o0] = v0;
+                            *(par_v4u *)&L.ring[mdA + o1] = v1;
+                        } else if (g8) {
+                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
+                            *(par_u64u *)&L.ring[mdA + o1] = ((uint64_t)v1.y << 32) | v1.x;
+                        } else {
+                            *(par_u32u *)&L.ring[mdA] = v0.x;
+                            *(par_u32u *)&L.ring[mdA + o1] = v1.x;
+                        }
+                    }
+                    wave_fence();
+                }
+                // short offsets (rare): steps of 8 / 4 / 1 bytes one after the other, because a step may
+                // read the previous step's bytes; last chunk re-anchored at the end (idempotent rewrite)
+                if (__ballot(mine && !fastc)) {
+                    const uint32_t step = w8 ? 8u : (w4 ? 4u : 1u);
+                    const uint32_t last = ml - step;
+                    const bool slow = mine && !fastc;
+                    for (uint32_t o = 0; __ballot(slow && o < ml); o += step) {
+                        if (STATS) sc[PS_MATCH_ITERS]++;
+                        if (slow && o < ml) {
+                            const uint32_t oo = min(o, last);
+                            if (w8) *(par_u64u *)&L.ring[mdA + oo] = *(const par_u64u *)&L.ring[msA + oo];
+                            else if (w4) *(par_u32u *)&L.ring[mdA + oo] = *(const par_u32u *)&L.ring[msA + oo];
+                            else L.ring[mdA + oo] = L.ring[msA + oo];
+                        }
+                        wave_fence();
+                    }
+                }
+                pending = pending && !mine;
+                done |= __ballot(mine);
+            }
+            wave_fence();
+            lap(PS_T_MATCH);
+
+            // ---------------- advance, 8. flush, slide ----------------
+            op = opNext;
+            ip = ipNext;
+            seqIdx += nseq;
+            dcur = dnext;
+            // the next window goes to LDS now (nobody reads the old one any more): this is where the wave
+            // waits for the prefetch, BEFORE the flush issues its stores, so that no later wait for a load
+            // also has to wait for those stores to be acknowledged
+            *(uint4 *)&L.win[16 * lane] = wnext;
+            wave_fence();
+            flush(op, false);
+            if (op - ringBase + (int)A + PAR_BATCH_OUT + 32 > PAR_RING) {
+                if (STATS) sc[PS_SLIDES]++;
+                const int newBase = (op - PAR_HIST) & ~15;
+                const int delta = newBase - ringBase;
+                const int n16 = (op - newBase + (int)A + 15) >> 4;
+                for (int k = lane; k < n16; k += LZ4_WAVE) {
+                    const uint4 v = *(const uint4 *)&L.ring[delta + 16 * k];
+                    wave_fence();
+                    *(uint4 *)&L.ring[16 * k] = v;
+                }
+                ringBase = newBase;
+                wave_fence();
+            }
+        }
+
+        // ================= slow path: the sequential decoder =================
+        // Either a sequence the hot loop does not take (one sequence, then back), or the tail of the
+        // block (and with it every end-of-block rule and every error code).
+        flush(op, true);
+        st.ip = ip; st.op = op; st.fast = true;
+        const bool tail = (iend - ip < 64 || cap - op < 128 || seqIdx >= nTok);
+        if (STATS && !tail) sc[PS_HANDOVERS]++;
+        lap(PS_T_FLUSH);
+        int r = decode_seq_run(st, tail ? 0 : 1, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+        if (r == SEQ_CONTINUE && (!st.fast || iend - st.ip < 64 || cap - st.op < 128))
+            r = decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+        lap(PS_T_SEQ);
+        r = uni(r);
+        if (r != SEQ_CONTINUE) { publish(); return r; }
+        ip = uni(st.ip); op = uni(st.op);                 // read back through memory: tell the compiler they are uniform
+        // Nothing lane-private has to survive the call: the lane id is re-read (an opaque definition, so that
+        // the values derived from it are rebuilt instead of being kept in registers across the call) and the
+        // window is fetched again.  decode_seq_run clobbers v0..v79; every VGPR that lives across the call
+        // sits above that and used to push the kernel to 124 VGPRs = 4 waves per SIMD.
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        wbase = (uintptr_t)(src + ip) & ~(uintptr_t)15;
+        wnext = fetch_window(wbase);
+        winStale = true;
+        seqIdx += 1;                                      // the sequential decoder took exactly one sequence
+        dcur = fetch_tok(seqIdx);
+        // reload the ring's history from global memory
+        wave_fence();
+        ringBase = (op > PAR_HIST) ? ((op - PAR_HIST) & ~15) : 0;
+        flushed = op;
+        for (int x = ringBase + lane; x < op; x += LZ4_WAVE) L.ring[x - ringBase + (int)A] = dst[x];
+        wave_fence();
+        lap(PS_T_SEQ);
+    }
+}
+
+} // namespace lz4dev

@@ -57,28 +57,26 @@ def gather_ordered(local, local_sizes, root=0, engine=None, group=None):
     torch.cumsum(local_sizes.to(torch.int64), 0, out=loff[1:])
     if rank != root:
         n = int(loff[-1].item())
-        dist.send(local[:n].contiguous(), dst=root, group=group)
+        dist.isend(local[:n].contiguous(), dst=root, group=group).wait()
         return None, goff
     total = int(goff[-1].item())
     out = torch.empty(total, dtype=torch.uint8, device=dev)
-    stages, reqs = {}, []
+    pending = []
     for g in range(G):
         if g == root:
             continue
         n = int(sizes[g].to(torch.int64).sum().item())
-        stages[g] = torch.empty(n, dtype=torch.uint8, device=dev)
-        reqs.append(dist.irecv(stages[g], src=g, group=group))
-    if out.is_cuda:
-        torch.cuda.current_stream().synchronize()                         # `out` is ready for the engine's stream
+        stage = torch.empty(n, dtype=torch.uint8, device=dev)
+        pending.append((g, stage, dist.irecv(stage, src=g, group=group)))
+    # The engine launches on torch's current stream (Engine._follow_torch), the stream req.wait() orders the
+    # receive against: no host synchronisation is needed between a receive and its interleave.
     interleave(local, loff, root, G, out, goff, engine)                  # overlaps with the receives
-    for r in reqs:
-        r.wait()
-    if out.is_cuda:
-        torch.cuda.current_stream().synchronize()                         # received bytes visible to the engine's stream
-    for g, buf in stages.items():
+    for g, stage, req in pending:                                         # each peer is placed as soon as it has arrived
+        req.wait()
         poff = torch.zeros(sizes[g].numel() + 1, dtype=torch.int64, device=dev)
         torch.cumsum(sizes[g].to(torch.int64), 0, out=poff[1:])
-        interleave(buf, poff, g, G, out, goff, engine)
-    if out.is_cuda and engine is not None:
-        engine.synchronize()
+        interleave(stage, poff, g, G, out, goff, engine)
+    del pending
+    if out.is_cuda:
+        torch.cuda.current_stream().synchronize()
     return out, goff

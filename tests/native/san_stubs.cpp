@@ -1,0 +1,16 @@
+// san_stubs.cpp -- kernel launchers of kernels.hip, stubbed for the CPU-only sanitizer build of the host
+// library (make asan / make tsan).  Never reached there: without a gfx950 device mi355lz4_create fails.
+#include "../../streamly-lz4_amd/csrc/kernels.h"
+
+#include <cstdlib>
+
+#define UNREACHABLE_LAUNCH abort()
+void launch_decode_seq(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_decode_par(const DecodeArgs &, unsigned long long *, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_decode_tok(const DecodeArgs &, unsigned long long *, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_decode_fixup_linked(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_encode(const EncodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_compact(const uint8_t *, size_t, const int32_t *, int, uint8_t *, size_t, uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_interleave(const uint8_t *, const uint64_t *, int, int, int, uint8_t *, const uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_index(const uint8_t *, uint64_t, const uint64_t *, int, int, int, int32_t *, uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_generate(int, uint8_t *, int, int, uint64_t, uint64_t, uint32_t, uint32_t, hipStream_t) { UNREACHABLE_LAUNCH; }

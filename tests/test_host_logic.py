@@ -153,3 +153,21 @@ def test_index_host(slz4, oracle):
                                         ulen.ctypes.data_as(i32p), 8, C.byref(nb)) == -6
     assert slz4.lib.mi355lz4_index_host(src.ctypes.data_as(u8p), src.size, 8, 0, boff.ctypes.data_as(u64p),
                                         ulen.ctypes.data_as(i32p), 3, C.byref(nb)) == -4
+
+
+def test_config1_alice29_plumbing(reference):
+    """BASELINE.json configs[0]: alice29.txt through the CPU reference with the semantics of
+    BENCH_STREAMLY_LZ4_STRATEGY=c+1+65536 (benchmark/Main.hs:196-205): 64 KiB reads, compressChunks
+    defaultBlockConfig 1, then the round trip.  Needs the Canterbury file; skipped when absent."""
+    import corpus
+    path = corpus.find("cantrbry/alice29.txt")
+    if path is None:
+        pytest.skip("cantrbry/alice29.txt not found under %s (no network here; set CANTERBURY_DIR)" % corpus.corpus_dir())
+    raw = open(path, "rb").read()
+    framed = reference.frame_compress(raw, 65536, 1, 8, True)
+    assert reference.frame_decompress(framed, len(raw), 8, 0, True) == raw
+    nblk = (len(raw) + 65535) // 65536
+    pos = 0
+    for _ in range(nblk):
+        pos += 8 + int.from_bytes(framed[pos:pos + 4], "little")
+    assert pos == len(framed)

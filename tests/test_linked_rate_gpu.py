@@ -58,3 +58,42 @@ def test_linked_stream_rate(engine, slz4, oracle, n_streams, blocks_per_stream):
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
+
+
+def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
+    """linked = 1 on a stream in which every block decodes standalone (what this engine's compressor writes,
+    and what the C++ mirror / LZ4_decompress_safe_continue always pass) must cost nothing measurable: the
+    fixup only walks REGIONS of failed blocks (cbits/lz4.c:2347-2355 semantics are unchanged)."""
+    import torch
+    dev = torch.device("cuda:0")
+    bl, nb = 65536, 16384
+    src = torch.empty(nb * bl, dtype=torch.uint8, device=dev)
+    engine.generate("lzsynth", src, bl, nb)
+    stride = slz4.slot_stride(bl, 8)
+    slots = torch.empty(nb * stride, dtype=torch.uint8, device=dev)
+    flen = torch.empty(nb, dtype=torch.int32, device=dev)
+    dense = torch.empty(nb * stride, dtype=torch.uint8, device=dev)
+    doff = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+    ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
+    out = torch.empty(nb * bl, dtype=torch.uint8, device=dev)
+    res = torch.empty(nb, dtype=torch.int32, device=dev)
+    engine.compress_batch_device(src, nb, bl, slots, stride, flen)
+    engine.compact_device(slots, stride, flen, nb, dense, nb * stride, doff)
+    e0, e1 = slz4.Event(), slz4.Event()
+    best = {}
+    for linked in (False, True, False, True):
+        t = 1e9
+        for _ in range(4):
+            engine.record(e0)
+            engine.decompress_batch_device(dense, nb * stride, doff, nb, out, ooff, res, linked=linked)
+            engine.record(e1)
+            engine.synchronize()
+            t = min(t, engine.elapsed_ms(e0, e1))
+        assert bool((res == bl).all().item()) and torch.equal(out, src)
+        best[linked] = min(best.get(linked, 1e9), t)
+    rec = {"test": "linked flag on independent blocks", "blocks": nb, "ms_linked0": round(best[False], 4),
+           "ms_linked1": round(best[True], 4)}
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)
+    assert best[True] <= best[False] * 1.02 + 0.02, rec

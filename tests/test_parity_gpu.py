@@ -27,7 +27,7 @@ def split_blocks(fr, meta=8):
 # --------------------------------------------------------------------------------------------
 # decode: bit-exact vs oracle / golden
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["lzsynth", "text", "random"])
 def test_decode_matches_oracle(engine, oracle, kind, decoder):
     engine.set_decoder(decoder)
@@ -67,7 +67,7 @@ def test_decode_linked_fixture(engine, linked_golden):
     assert blen == [linked_golden["block_len"]] * 4 and sha(out) == linked_golden["raw_sha256"]
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_malformed_codes(engine, golden, decoder):
     """Negative codes -(ip-src)-1 (cbits/lz4.c:2163) equal the reference's, for both decoder kernels."""
     engine.set_decoder(decoder)
@@ -85,7 +85,7 @@ def test_decode_malformed_codes(engine, golden, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
     """Mutated / truncated blocks, batched: every status and every decoded byte equals the oracle's."""
     engine.set_decoder(decoder)
@@ -122,7 +122,7 @@ def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_huge_length_fields(engine, oracle, decoder):
     """Length fields that are multi-megabyte runs of 0xFF (lengths >= 2^31): same code as the oracle, and
     nothing is written outside the block's output (cbits/lz4.c:1811-1818, 1854-1858, 2064-2065)."""
@@ -198,6 +198,34 @@ def test_encode_size_vs_reference(engine, oracle):
                 ours = len(engine.compress_batch([data[i * bl:(i + 1) * bl] for i in range(n)], accel=accel)[0])
                 ref = len(oracle.frame_compress(data, bl, accel, 8, True))
                 assert ours <= ref * tol, (kind, bl, accel, ours, ref)
+
+
+def test_compact_honours_dense_cap(engine, slz4, oracle):
+    """mi355lz4_compact_device never writes at or past denseCap: blocks that do not fit are skipped and
+    denseOff[nBlocks] still reports the bytes the whole stream needs."""
+    import torch
+    dev = torch.device("cuda:0")
+    bl, n = 4096, 16
+    raw = oracle.gen("random", n, bl).tobytes()
+    src = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)
+    stride = slz4.slot_stride(bl, 8)
+    slots = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    flen = torch.empty(n, dtype=torch.int32, device=dev)
+    engine.compress_batch_device(src, n, bl, slots, stride, flen)
+    engine.synchronize()
+    need = int(flen.sum().item())
+    cap = need // 2                                             # undersized on purpose
+    dense = torch.full((need + 64,), 0xA5, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    engine.compact_device(slots, stride, flen, n, dense, cap, doff)
+    engine.synchronize()
+    assert int(doff[-1].item()) == need                          # the caller can see it did not fit
+    assert bool((dense[cap:] == 0xA5).all().item())              # nothing at or past denseCap was touched
+    fitted = [i for i in range(n) if int(doff[i + 1].item()) <= cap]
+    assert fitted and len(fitted) < n
+    for i in fitted:
+        a, b = int(doff[i].item()), int(doff[i + 1].item())
+        assert torch.equal(dense[a:b], slots[i * stride:i * stride + (b - a)])
 
 
 def test_encode_special_inputs(engine, oracle):
@@ -415,7 +443,7 @@ def test_ragged_batch_roundtrip(engine, oracle):
         assert oracle.decompress_block(fr[pos + 8:pos + f], len(b)) == (len(b), b)
         pos += f
     # and the GPU decodes the whole ragged stream, both kernels
-    for dec in (1, 2):
+    for dec in (1, 2, 3):
         engine.set_decoder(dec)
         out, blen = engine.decompress_batch(fr)
         assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
@@ -501,7 +529,7 @@ def _decode_streams(engine, frs, linked_mode):
     return out[: int(ooff_h[-1])].cpu().numpy().tobytes(), res.cpu().tolist(), ulen, first
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_linked_streams_many(engine, oracle, decoder):
     engine.set_decoder(decoder)
     try:
