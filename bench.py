@@ -62,6 +62,55 @@ def canterbury_large(n_bytes):
     return b"".join(parts), "Canterbury large (bible.txt, E.coli, world192.txt cycled)"
 
 
+def host_api_rates(S, eng, src, BL, kind):
+    """PCIe-inclusive rate of the host-buffer C API (what the Haskell shim binds) on the first 512 MiB of the
+    same stream: pageable caller memory (staged through pinned slots) and page-locked caller memory (DMA
+    straight from / to the caller's buffers).  Never `value`: the inputs start in host memory here."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    L = S.lib
+    u8p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    nb = min(src.numel() // BL, (512 << 20) // BL)
+    cap = nb * (S.compress_bound(BL) + 8)
+    res = {"MiB_per_call": nb * BL >> 20, "link_GBps_one_direction": None}
+    try:
+        h = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+        d = torch.empty(256 << 20, dtype=torch.uint8, device=src.device)
+        d.copy_(h, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter(); d.copy_(h, non_blocking=True); torch.cuda.synchronize()
+        res["link_GBps_one_direction"] = round(h.numel() / (time.perf_counter() - t0) / 1e9, 1)
+        del h, d
+    except Exception:
+        pass
+    for mem in ("pageable", "pinned"):
+        mk = (lambda n: torch.empty(n, dtype=torch.uint8).pin_memory()) if mem == "pinned" else (lambda n: torch.empty(n, dtype=torch.uint8))
+        host_t, framed_t, out_t = mk(nb * BL), mk(cap), mk(nb * BL)
+        host_t.copy_(src[: nb * BL].cpu())
+        ptrs = (u8p * nb)(*[C.cast(host_t.data_ptr() + i * BL, u8p) for i in range(nb)])
+        lens = np.full(nb, BL, dtype=np.int32)
+        flen = np.zeros(nb, dtype=np.int32); st = np.zeros(nb, dtype=np.int32); blen = np.zeros(nb, dtype=np.int32)
+        olen, dlen, got = C.c_size_t(), C.c_size_t(), C.c_int()
+        tc = td = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = L.mi355lz4_compress_batch(eng.ctx, ptrs, lens.ctypes.data_as(i32p), nb, 1, 8, C.cast(framed_t.data_ptr(), u8p), cap,
+                                           C.byref(olen), flen.ctypes.data_as(i32p), st.ctypes.data_as(i32p))
+            t1 = time.perf_counter()
+            if rc != 0:
+                return {"error": (L.mi355lz4_last_error() or b"").decode()}
+            rc = L.mi355lz4_decompress_batch(eng.ctx, C.cast(framed_t.data_ptr(), u8p), olen.value, 8, 0, 1, None, 0,
+                                             C.cast(out_t.data_ptr(), u8p), nb * BL, C.byref(dlen), blen.ctypes.data_as(i32p), nb, C.byref(got))
+            t2 = time.perf_counter()
+            if rc != 0 or dlen.value != nb * BL:
+                return {"error": (L.mi355lz4_last_error() or b"").decode()}
+            tc, td = min(tc, t1 - t0), min(td, t2 - t1)
+        if not torch.equal(out_t, host_t):
+            return {"error": "host API round trip mismatch"}
+        res[mem] = {"compress_GBps": round(nb * BL / tc / 1e9, 2), "decompress_GBps": round(nb * BL / td / 1e9, 2)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +125,7 @@ def main():
     ap.add_argument("--cpu-sample-blocks", type=int, default=0)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL ordered gather + its verification")
     ap.add_argument("--no-extra", action="store_true", help="skip the round-trip / compress figures measured after the timed steps")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-buffer API figures (N=1)")
     args = ap.parse_args()
 
     import torch
@@ -325,6 +375,8 @@ def main():
     }
     if extra is not None:
         line["roundtrip"] = extra
+    if world == 1 and not args.no_host_api and kind != "canterbury-large":
+        line["host_api_pcie_inclusive"] = host_api_rates(S, eng, src, BL, kind)
     if gather is not None:
         # compute-only is `value`; compute+gather adds one ordered gather per compress pass
         cm = (extra or {}).get("kernels_ms", {}).get("compress")

@@ -10,10 +10,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -150,6 +152,9 @@ struct mi355lz4_ctx {
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
     DevBuf tok, tokOff, tokCnt, tokSizes;   // token lists of the list-driven decoder
     DevBuf pinIn, pinOut;   // pinned host staging
+    DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
+    hipStream_t sIn = nullptr, sOut = nullptr;   // copy streams of the pipelined host-buffer API (created on first use)
+    hipStream_t sK[2] = {nullptr, nullptr};   // compute streams: kernels of consecutive groups overlap
     unsigned long long *stats = nullptr;   // diagnostics: device counters of the lane-parallel decoder (off by default)
 };
 
@@ -294,6 +299,10 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
         dev_release(*b);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
+    pin_release(c->pinMeta);
+    if (c->sIn) hipStreamDestroy(c->sIn);
+    if (c->sOut) hipStreamDestroy(c->sOut);
+    for (hipStream_t &k : c->sK) if (k) hipStreamDestroy(k);
     if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -402,7 +411,7 @@ extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, si
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
-                         uint32_t dict0Len, const int32_t *streamFirst = nullptr, int nStreams = 0)
+                         uint32_t dict0Len, const int32_t *streamFirst = nullptr, int nStreams = 0, int lookBack = 0)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
     if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || fixedUncomp < 0)
@@ -415,7 +424,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.headerKind = headerKind; a.fixedUncomp = fixedUncomp; a.linked = linked ? 1 : 0;
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
-    a.streamFirst = streamFirst; a.nStreams = nStreams;
+    a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
     a.tok = nullptr; a.tokOff = nullptr; a.tokCnt = nullptr; a.tokSizes = nullptr; a.tokCap = 0;
     if (c->decoder == 3) {
         // every sequence takes >= 3 compressed bytes: framedLen / 3 entries (+2 per block) hold every list of
@@ -530,6 +539,99 @@ extern "C" int mi355lz4_event_elapsed_ms(void *start, void *stop, float *ms)
     return MI355LZ4_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Pipelined host-buffer calls.  A call is cut into groups of blocks; the H2D copy of
+// group i+1, the kernels of group i and the D2H copy of group i-1 run on three streams, and the CPU copies
+// between pageable caller memory and the pinned staging slots run meanwhile on the copy pool.  Caller
+// memory that is already page-locked (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is
+// handed to the DMA engines directly.
+// ---------------------------------------------------------------------------
+// The pipelined calls keep the caller's stream, two copy streams and two compute streams busy; HIP multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialize
+// (measured: compress 33 -> 41 GB/s with 8).  Ask for 8 unless the process says otherwise; it only takes
+// effect if this library is loaded before the HIP runtime initialises.
+__attribute__((constructor)) static void mi355lz4_hw_queues()
+{
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
+static bool pipe_trace()
+{
+    static const bool v = [] { const char *e = getenv("MI355LZ4_TRACE"); return e && atoi(e); }();
+    return v;
+}
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+#define PTRACE(...) do { if (pipe_trace()) { fprintf(stderr, "[%10.3f] ", now_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
+
+static size_t group_bytes()
+{
+    static const size_t v = [] {
+        const char *e = getenv("MI355LZ4_GROUP_MB");
+        const long mb = e ? atol(e) : 64;
+        return (size_t)((mb < 1) ? 1 : (mb > 4096 ? 4096 : mb)) << 20;
+    }();
+    return v;
+}
+
+static bool host_range_is_pinned(const void *p, size_t n)
+{
+    if (!p || !n) return false;
+    if (const char *e = getenv("MI355LZ4_NO_DIRECT")) if (atoi(e)) return false;
+    hipPointerAttribute_t at;
+    for (const uint8_t *q : {(const uint8_t *)p, (const uint8_t *)p + (n - 1)}) {
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+static int pipe_streams(mi355lz4_ctx *c)
+{
+    if (!c->sIn) HIP_TRY(hipStreamCreateWithFlags(&c->sIn, hipStreamNonBlocking));
+    if (!c->sOut) HIP_TRY(hipStreamCreateWithFlags(&c->sOut, hipStreamNonBlocking));
+    for (hipStream_t &k : c->sK) if (!k) HIP_TRY(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
+    return 0;
+}
+
+// run the device-API entry points on another stream of the same engine for the duration of a scope
+struct StreamSwap {
+    mi355lz4_ctx *c;
+    hipStream_t saved;
+    StreamSwap(mi355lz4_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
+// events of one pipelined call, destroyed together
+struct EventSet {
+    std::vector<hipEvent_t> ev;
+    ~EventSet() { for (hipEvent_t e : ev) if (e) hipEventDestroy(e); }
+    int make(hipEvent_t *out)
+    {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev.push_back(e);
+        *out = e;
+        return 0;
+    }
+};
+
+// never return from a pipelined call with work in flight that still references caller or ctx buffers
+struct DrainOnExit {
+    mi355lz4_ctx *c;
+    ~DrainOnExit()
+    {
+        if (c->sIn) hipStreamSynchronize(c->sIn);
+        hipStreamSynchronize(c->stream);
+        for (hipStream_t k : c->sK) if (k) hipStreamSynchronize(k);
+        if (c->sOut) hipStreamSynchronize(c->sOut);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // host-buffer batched API
 // ---------------------------------------------------------------------------
@@ -552,6 +654,7 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
 
     size_t total = 0;
     int maxLen = 0;
+    bool contiguous = true;                    // blocks back to back in caller memory, every start 16-aligned
     std::vector<uint64_t> offs((size_t)nBlocks);
     for (int i = 0; i < nBlocks; i++) {
         // compressChunk's size check, Internal/LZ4.hs:237-241 (BlockHasSize limit = LZ4_MAX_INPUT_SIZE)
@@ -559,65 +662,138 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
             return fail(MI355LZ4_E_ARG, "compress_batch: block %d length %d exceeds the maximum block size", i, srcLen[i]);
         if (srcLen[i] > 0 && !src[i]) return fail(MI355LZ4_E_ARG, "compress_batch: block %d is null", i);
         offs[(size_t)i] = total;
+        if (i > 0 && src[i] != src[0] + total) contiguous = false;
         total += ((size_t)srcLen[i] + 15) & ~(size_t)15;   // 16-aligned block starts
         if (srcLen[i] > maxLen) maxLen = srcLen[i];
     }
     const size_t stride = mi355lz4_slot_stride(maxLen, headerKind);
+
+    // groups of consecutive blocks, about group_bytes() of input each
+    std::vector<int> gFirst;
+    {
+        size_t acc = 0;
+        for (int i = 0; i < nBlocks; i++) {
+            if (i == 0 || acc >= group_bytes()) { gFirst.push_back(i); acc = 0; }
+            acc += (size_t)srcLen[i];
+        }
+        gFirst.push_back(nBlocks);
+    }
+    const int G = (int)gFirst.size() - 1;
+    size_t maxIn = 0, maxBlocksG = 0;
+    for (int g = 0; g < G; g++) {
+        const size_t lo = offs[(size_t)gFirst[g]], hi = (gFirst[g + 1] < nBlocks) ? offs[(size_t)gFirst[g + 1]] : total;
+        if (hi - lo > maxIn) maxIn = hi - lo;
+        if ((size_t)(gFirst[g + 1] - gFirst[g]) > maxBlocksG) maxBlocksG = (size_t)(gFirst[g + 1] - gFirst[g]);
+    }
+    const bool directIn = contiguous && host_range_is_pinned(src[0], total);
+    const bool directOut = host_range_is_pinned(framedOut, cap);
+
     int r;
-    if ((r = pin_reserve(c->pinIn, total + 16))) return r;
+    if ((r = pipe_streams(c))) return r;
+    if (!directIn && (r = pin_reserve(c->pinIn, 2 * (maxIn + 16)))) return r;
+    if (!directOut && (r = pin_reserve(c->pinOut, 2 * maxBlocksG * stride))) return r;
+    if ((r = pin_reserve(c->pinMeta, (size_t)nBlocks * 4 + (size_t)G * 8))) return r;
     if ((r = dev_reserve(c->in, total + 16))) return r;
     if ((r = dev_reserve(c->offA, (size_t)nBlocks * 8))) return r;
     if ((r = dev_reserve(c->lenA, (size_t)nBlocks * 4))) return r;
     if ((r = dev_reserve(c->lenB, (size_t)nBlocks * 4))) return r;
     if ((r = dev_reserve(c->slots, (size_t)nBlocks * stride))) return r;
     if ((r = dev_reserve(c->dense, (size_t)nBlocks * stride))) return r;
-    if ((r = dev_reserve(c->offB, ((size_t)nBlocks + 1) * 8))) return r;
+    if ((r = dev_reserve(c->offB, ((size_t)nBlocks + (size_t)G) * 8))) return r;
 
-    uint8_t *stage = (uint8_t *)c->pinIn.p;
-    {
-        size_t sent = 0;                       // staging bytes already handed to the DMA engine
-        std::vector<CopyTask> tasks;
-        for (int i = 0; i < nBlocks; i++) {
-            if (srcLen[i] > 0) tasks.push_back({stage + offs[(size_t)i], src[i], (size_t)srcLen[i]});
-            const size_t filled = (i + 1 < nBlocks) ? (size_t)offs[(size_t)i + 1] : total;
-            if (filled - sent >= kStageChunk || i + 1 == nBlocks) {
-                copy_pool().run(tasks);
-                tasks.clear();
-                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + sent, stage + sent, filled - sent, hipMemcpyHostToDevice, c->stream));
-                sent = filled;
-            }
-        }
-    }
+    DrainOnExit drain{c};
+    EventSet evs;
     HIP_TRY(hipMemcpyAsync(c->offA.p, offs.data(), (size_t)nBlocks * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->lenA.p, srcLen, (size_t)nBlocks * 4, hipMemcpyHostToDevice, c->stream));
     // offs / srcLen are pageable: make sure the copies have consumed them before they go away
     HIP_TRY(hipStreamSynchronize(c->stream));
 
-    r = mi355lz4_compress_batch_device(c, (const uint8_t *)c->in.p, (const uint64_t *)c->offA.p,
-                                       (const int32_t *)c->lenA.p, 0, maxLen, nBlocks, accel, headerKind,
-                                       (uint8_t *)c->slots.p, stride, (int32_t *)c->lenB.p);
-    if (r) return r;
-    r = mi355lz4_compact_device(c, (const uint8_t *)c->slots.p, stride, (const int32_t *)c->lenB.p, nBlocks,
-                                (uint8_t *)c->dense.p, (size_t)nBlocks * stride, (uint64_t *)c->offB.p);
-    if (r) return r;
-
-    std::vector<int32_t> flen((size_t)nBlocks);
-    uint64_t totalOut = 0;
-    HIP_TRY(hipMemcpyAsync(flen.data(), c->lenB.p, (size_t)nBlocks * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&totalOut, (const uint8_t *)c->offB.p + (size_t)nBlocks * 8, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-
+    int32_t *flenPin = (int32_t *)c->pinMeta.p;                              // framed length of every block
+    uint64_t *totPin = (uint64_t *)((uint8_t *)c->pinMeta.p + (size_t)nBlocks * 4);   // compressed bytes of every group
+    std::vector<hipEvent_t> evIn((size_t)G), evK((size_t)G), evOut((size_t)G);
+    std::vector<size_t> outAt((size_t)G, 0), outN((size_t)G, 0);
+    size_t outPos = 0;
     int bad = 0;
-    for (int i = 0; i < nBlocks; i++) {
-        const int32_t f = flen[(size_t)i];
-        if (blockFramedLen) blockFramedLen[i] = f;
-        if (status) status[i] = (f > headerKind) ? f - headerKind : 0;
-        if (f <= headerKind) bad++;
+    bool overflow = false;
+
+    // Phase 1 -- input.  A block takes the encoder ~2 ms whatever else runs (it is latency-bound), and a
+    // group of a few hundred blocks fills a fraction of the chip, so the kernels of consecutive groups go to
+    // different compute streams and overlap each other as well as the copies.
+    for (int g = 0; g < G; g++) {
+        const int b0 = gFirst[g], b1 = gFirst[g + 1];
+        const size_t lo = offs[(size_t)b0], hi = (b1 < nBlocks) ? offs[(size_t)b1] : total;
+        if ((r = evs.make(&evIn[(size_t)g])) || (r = evs.make(&evK[(size_t)g])) || (r = evs.make(&evOut[(size_t)g]))) return r;
+        if (directIn) {
+            HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, src[0] + lo, hi - lo, hipMemcpyHostToDevice, c->sIn));
+        } else {
+            uint8_t *slot = (uint8_t *)c->pinIn.p + (size_t)(g & 1) * (maxIn + 16);
+            if (g >= 2) HIP_TRY(hipEventSynchronize(evIn[(size_t)g - 2]));   // the copy that last read this slot
+            std::vector<CopyTask> tasks;
+            for (int i = b0; i < b1; i++)
+                if (srcLen[i] > 0) tasks.push_back({slot + (offs[(size_t)i] - lo), src[i], (size_t)srcLen[i]});
+            copy_pool().run(tasks);
+            HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, slot, hi - lo, hipMemcpyHostToDevice, c->sIn));
+        }
+        HIP_TRY(hipEventRecord(evIn[(size_t)g], c->sIn));
+        StreamSwap on(c, c->sK[g & 1]);
+        HIP_TRY(hipStreamWaitEvent(c->stream, evIn[(size_t)g], 0));
+        PTRACE("compress: group %d H2D enqueued (%zu bytes, direct %d)", g, hi - lo, (int)directIn);
+        r = mi355lz4_compress_batch_device(c, (const uint8_t *)c->in.p, (const uint64_t *)c->offA.p + b0,
+                                           (const int32_t *)c->lenA.p + b0, 0, maxLen, b1 - b0, accel, headerKind,
+                                           (uint8_t *)c->slots.p + (size_t)b0 * stride, stride, (int32_t *)c->lenB.p + b0);
+        if (r) return r;
+        uint64_t *goff = (uint64_t *)c->offB.p + b0 + g;                       // b1 - b0 + 1 offsets of this group
+        r = mi355lz4_compact_device(c, (const uint8_t *)c->slots.p + (size_t)b0 * stride, stride,
+                                    (const int32_t *)c->lenB.p + b0, b1 - b0, (uint8_t *)c->dense.p + (size_t)b0 * stride,
+                                    (size_t)(b1 - b0) * stride, goff);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(flenPin + b0, (const int32_t *)c->lenB.p + b0, (size_t)(b1 - b0) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(totPin + g, goff + (b1 - b0), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(evK[(size_t)g], c->stream));
+    }
+    // Phase 2 -- output, once the last input copy is through: on this link both directions together run
+    // at ~39 GB/s each against 57 GB/s for one alone (scripts/pcie_rate.py) and the output is the small
+    // side, so it only overlaps the tail of the kernels.  D2H of group t while the pool copies group t-1 out.
+    // The output copies go to the INPUT copy stream, behind the last input copy: HIP multiplexes streams onto four
+    // hardware queues by default, and the caller's stream, one copy stream and two compute streams use them up.
+    // Data that barely compresses sends back as much as it took in: then the two directions do overlap (own stream).
+    hipStream_t so = c->sIn;
+    for (int t = 0; t < G + 1; t++) {
+        if (t < G) {
+            const int g = t, b0 = gFirst[g], b1 = gFirst[g + 1];
+            HIP_TRY(hipEventSynchronize(evK[(size_t)g]));
+            if (g == 0) {
+                const size_t in0 = ((gFirst[1] < nBlocks) ? offs[(size_t)gFirst[1]] : total) - offs[0];
+                if ((size_t)totPin[0] * 8 > in0 * 5) so = c->sOut;
+            }
+            PTRACE("compress: group %d kernels done", g);
+            for (int i = b0; i < b1; i++) {
+                const int32_t f = flenPin[i];
+                if (blockFramedLen) blockFramedLen[i] = f;
+                if (status) status[i] = (f > headerKind) ? f - headerKind : 0;
+                if (f <= headerKind) bad++;
+            }
+            outAt[(size_t)g] = outPos;
+            outN[(size_t)g] = (size_t)totPin[g];
+            outPos += outN[(size_t)g];
+            if (outPos > cap) overflow = true;
+            if (!bad && !overflow && outN[(size_t)g]) {
+                uint8_t *dst = directOut ? framedOut + outAt[(size_t)g] : (uint8_t *)c->pinOut.p + (size_t)(g & 1) * maxBlocksG * stride;
+                HIP_TRY(hipMemcpyAsync(dst, (const uint8_t *)c->dense.p + (size_t)b0 * stride, outN[(size_t)g], hipMemcpyDeviceToHost, so));
+            }
+            HIP_TRY(hipEventRecord(evOut[(size_t)g], so));
+        }
+        if (t >= 1) {
+            const int g = t - 1;
+            HIP_TRY(hipEventSynchronize(evOut[(size_t)g]));
+            PTRACE("compress: group %d D2H done (%zu bytes)", g, outN[(size_t)g]);
+            if (!directOut && !bad && !overflow && outN[(size_t)g])
+                copy_pool().copy(framedOut + outAt[(size_t)g], (const uint8_t *)c->pinOut.p + (size_t)(g & 1) * maxBlocksG * stride, outN[(size_t)g]);
+        }
     }
     if (bad) return fail(MI355LZ4_E_BLOCK, "compress_batch: %d block(s) failed", bad);
-    if (totalOut > cap) return fail(MI355LZ4_E_CAPACITY, "compress_batch: need %llu bytes, have %zu", (unsigned long long)totalOut, cap);
-    if ((r = d2h_staged(c, framedOut, c->dense.p, (size_t)totalOut))) return r;
-    *outLen = (size_t)totalOut;
+    if (overflow) return fail(MI355LZ4_E_CAPACITY, "compress_batch: need %llu bytes, have %zu", (unsigned long long)outPos, cap);
+    *outLen = outPos;
     return MI355LZ4_OK;
 }
 
@@ -652,6 +828,11 @@ static int decompress_host(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLe
                            const int32_t *streamFirst, int nStreams,
                            uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
                            int maxBlocks, int *nBlocksOut);
+static int decompress_host_pipelined(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                     int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
+                                     const std::vector<uint64_t> &boff, const std::vector<int32_t> &ulen,
+                                     const std::vector<uint64_t> &ooff, int n, uint8_t *out, size_t *outLen,
+                                     int32_t *blockLen, int *nBlocksOut);
 
 extern "C" int mi355lz4_decompress_batch(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
                                          int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
@@ -703,6 +884,10 @@ static int decompress_host(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLe
         total += (uint64_t)ulen[(size_t)i];
     }
     ooff[(size_t)n] = total;
+    // the pipelined path writes every block at its capacity offset: it needs room for that layout and one stream
+    if (!streamFirst && cap >= total && total > 0)
+        return decompress_host_pipelined(c, framedIn, inLen, headerKind, fixedUncomp, linked, dict, dictLen, boff, ulen,
+                                         ooff, n, out, outLen, blockLen, nBlocksOut);
     if ((r = dev_reserve(c->in, inLen + 16))) return r;
     if ((r = dev_reserve(c->out, (size_t)total + 16))) return r;
     if ((r = dev_reserve(c->offA, (size_t)n * 8))) return r;
@@ -760,6 +945,128 @@ static int decompress_host(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLe
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    *outLen = (size_t)need;
+    return MI355LZ4_OK;
+}
+
+
+// One stream, output laid out at capacity offsets: groups of blocks flow through H2D -> decode (-> linked
+// fixup of the group, which looks back into the groups before it) -> D2H on three streams.
+static int decompress_host_pipelined(mi355lz4_ctx *c, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                     int fixedUncomp, int linked, const uint8_t *dict, int dictLen,
+                                     const std::vector<uint64_t> &boff, const std::vector<int32_t> &ulen,
+                                     const std::vector<uint64_t> &ooff, int n, uint8_t *out, size_t *outLen,
+                                     int32_t *blockLen, int *nBlocksOut)
+{
+    const uint64_t total = ooff[(size_t)n];
+    std::vector<int> gFirst;
+    {
+        size_t acc = 0;
+        for (int i = 0; i < n; i++) {
+            if (i == 0 || acc >= group_bytes()) { gFirst.push_back(i); acc = 0; }
+            acc += (size_t)ulen[(size_t)i];
+        }
+        gFirst.push_back(n);
+    }
+    const int G = (int)gFirst.size() - 1;
+    auto in_lo = [&](int b) -> size_t { return (b < n) ? (size_t)boff[(size_t)b] : inLen; };
+    size_t maxIn = 0, maxOut = 0;
+    for (int g = 0; g < G; g++) {
+        maxIn = std::max(maxIn, in_lo(gFirst[g + 1]) - in_lo(gFirst[g]));
+        maxOut = std::max(maxOut, (size_t)(ooff[(size_t)gFirst[g + 1]] - ooff[(size_t)gFirst[g]]));
+    }
+    const bool directIn = host_range_is_pinned(framedIn, inLen);
+    const bool directOut = host_range_is_pinned(out, (size_t)total);
+    int r;
+    if ((r = pipe_streams(c))) return r;
+    if (!directIn && (r = pin_reserve(c->pinIn, 2 * (maxIn + 16)))) return r;
+    if (!directOut && (r = pin_reserve(c->pinOut, 2 * (maxOut + 16)))) return r;
+    if ((r = pin_reserve(c->pinMeta, (size_t)n * 4))) return r;
+    if ((r = dev_reserve(c->in, inLen + 16))) return r;
+    if ((r = dev_reserve(c->out, (size_t)total + 16))) return r;
+    if ((r = dev_reserve(c->offA, (size_t)n * 8))) return r;
+    if ((r = dev_reserve(c->offB, ((size_t)n + 1) * 8))) return r;
+    if ((r = dev_reserve(c->res, (size_t)n * 4))) return r;
+
+    DrainOnExit drain{c};
+    EventSet evs;
+    uint32_t dlen = 0;
+    if (linked && dict && dictLen > 0) {                    // see decompress_host: only the last 64 KiB matter
+        dlen = (dictLen > 65536) ? 65536u : (uint32_t)dictLen;
+        if ((r = dev_reserve(c->scratch, 65536 + 16))) return r;
+        HIP_TRY(hipMemcpyAsync(c->scratch.p, dict + (dictLen - (int)dlen), dlen, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->offA.p, boff.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->offB.p, ooff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    int32_t *resPin = (int32_t *)c->pinMeta.p;
+    std::vector<hipEvent_t> evIn((size_t)G), evK((size_t)G), evOut((size_t)G);
+    for (int t = 0; t < G + 1; t++) {
+        if (t < G) {                                                           // ---- stage A, group t
+            const int g = t, b0 = gFirst[g], b1 = gFirst[g + 1];
+            const size_t lo = in_lo(b0), hi = in_lo(b1);
+            if ((r = evs.make(&evIn[(size_t)g])) || (r = evs.make(&evK[(size_t)g])) || (r = evs.make(&evOut[(size_t)g]))) return r;
+            if (directIn) {
+                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, framedIn + lo, hi - lo, hipMemcpyHostToDevice, c->sIn));
+            } else {
+                uint8_t *slot = (uint8_t *)c->pinIn.p + (size_t)(g & 1) * (maxIn + 16);
+                if (g >= 2) HIP_TRY(hipEventSynchronize(evIn[(size_t)g - 2]));
+                copy_pool().copy(slot, framedIn + lo, hi - lo);
+                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, slot, hi - lo, hipMemcpyHostToDevice, c->sIn));
+            }
+            HIP_TRY(hipEventRecord(evIn[(size_t)g], c->sIn));
+            HIP_TRY(hipStreamWaitEvent(c->stream, evIn[(size_t)g], 0));
+            // the group's blocks, with the whole framed buffer as bounds and the blocks before it as look-back
+            r = decode_device(c, (const uint8_t *)c->in.p, inLen, (const uint64_t *)c->offA.p + b0, b1 - b0, headerKind,
+                              fixedUncomp, linked, (uint8_t *)c->out.p, (const uint64_t *)c->offB.p + b0, nullptr,
+                              (int32_t *)c->res.p + b0, dlen ? (const uint8_t *)c->scratch.p : nullptr, dlen, nullptr, 0, b0);
+            if (r) return r;
+            HIP_TRY(hipMemcpyAsync(resPin + b0, (const int32_t *)c->res.p + b0, (size_t)(b1 - b0) * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(evK[(size_t)g], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->sOut, evK[(size_t)g], 0));
+            const size_t olo = (size_t)ooff[(size_t)b0], ohi = (size_t)ooff[(size_t)b1];
+            if (ohi > olo) {
+                if (directOut) {
+                    HIP_TRY(hipMemcpyAsync(out + olo, (const uint8_t *)c->out.p + olo, ohi - olo, hipMemcpyDeviceToHost, c->sOut));
+                } else {
+                    // slot g & 1 was emptied by stage C of group g - 2, one iteration ago
+                    uint8_t *slot = (uint8_t *)c->pinOut.p + (size_t)(g & 1) * (maxOut + 16);
+                    HIP_TRY(hipMemcpyAsync(slot, (const uint8_t *)c->out.p + olo, ohi - olo, hipMemcpyDeviceToHost, c->sOut));
+                }
+            }
+            HIP_TRY(hipEventRecord(evOut[(size_t)g], c->sOut));
+        }
+        if (t >= 1) {                                                          // ---- stage C, group t-1
+            const int g = t - 1, b0 = gFirst[g], b1 = gFirst[g + 1];
+            HIP_TRY(hipEventSynchronize(evOut[(size_t)g]));
+            const size_t olo = (size_t)ooff[(size_t)b0], ohi = (size_t)ooff[(size_t)b1];
+            if (!directOut && ohi > olo)
+                copy_pool().copy(out + olo, (const uint8_t *)c->pinOut.p + (size_t)(g & 1) * (maxOut + 16), ohi - olo);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    int bad = 0;
+    bool full = true;
+    uint64_t need = 0;
+    for (int i = 0; i < n; i++) {
+        const int32_t ri = resPin[i];
+        if (blockLen) blockLen[i] = ri;
+        if (ri < 0) bad++; else need += (uint64_t)ri;
+        if (ri != ulen[(size_t)i]) full = false;
+    }
+    *nBlocksOut = n;
+    if (bad) return fail(MI355LZ4_E_BLOCK, "decompress_batch: %d block(s) failed", bad);
+    if (!full) {
+        // a block may decode to fewer bytes than its capacity: pack the blocks back to back, in place
+        uint64_t w = 0;
+        for (int i = 0; i < n; i++) {
+            const uint64_t len = (uint64_t)resPin[i];
+            if (len && w != ooff[(size_t)i]) memmove(out + w, out + ooff[(size_t)i], (size_t)len);
+            w += len;
+        }
+    }
     *outLen = (size_t)need;
     return MI355LZ4_OK;
 }

@@ -28,6 +28,8 @@ struct DecodeArgs {
     uint32_t dict0Len;
     const int32_t *streamFirst;   // linked only: stream s = blocks [streamFirst[s], streamFirst[s+1]); null = one stream
     int nStreams;
+    int lookBack;                 // linked, one stream: blocks of the SAME stream that precede block 0 in result[] /
+                                  // outOff[] (already final); lets a long stream be decoded range by range
     // token lists (tok_parse.hpp): block i's list is tok[tokOff[i] .. tokOff[i] + tokCnt[i]), one u16 per
     // sequence = its compressed length; tokCap = entries allocated in tok
     uint16_t *tok;

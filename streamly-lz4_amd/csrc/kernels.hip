@@ -361,13 +361,19 @@ __global__ PAR_OCC void k_decode_fixup_regions(DecodeArgs a)
     const int blk = base + lane;
     const int r0 = (blk < a.nBlocks) ? a.result[blk] : 1;
     const int rp = (blk > 0 && blk < a.nBlocks) ? a.result[blk - 1] : 1;
+    // block 0 of a range continues whatever region the blocks before the range ended in
     const bool startsRegion = blk < a.nBlocks && r0 <= 0 && (blk == 0 || rp > 0);
     for (uint64_t m = __ballot(startsRegion); m; m &= m - 1) {
         int f = base + (int)__builtin_ctzll(m);
         const uint8_t *dict = nullptr;
         uint32_t dictLen = 0;
-        if (f == 0) { if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; } }
-        else { dict = a.out + a.outOff[f - 1]; dictLen = (uint32_t)uni(a.result[f - 1]); }
+        if (f == 0) {
+            if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
+            for (int j = 1; j <= a.lookBack; j++) {               // the last block before the range that produced output
+                const int rj = uni(a.result[-j]);
+                if (rj > 0) { dict = a.out + a.outOff[-j]; dictLen = (uint32_t)rj; break; }
+            }
+        } else { dict = a.out + a.outOff[f - 1]; dictLen = (uint32_t)uni(a.result[f - 1]); }
         for (; f < a.nBlocks; f++) {
             int r = uni(a.result[f]);
             if (r > 0) break;                                     // end of the region
