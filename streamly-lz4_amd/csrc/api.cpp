@@ -151,6 +151,7 @@ struct mi355lz4_ctx {
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
     DevBuf tok, tokOff, tokCnt, tokSizes;   // token lists of the list-driven decoder
+    DevBuf tolPool, tolMeta;                // deferred-copy decode of a long linked stream (linked_replay.hpp)
     DevBuf pinIn, pinOut;   // pinned host staging
     DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
     hipStream_t sIn = nullptr, sOut = nullptr;   // copy streams of the pipelined host-buffer API (created on first use)
@@ -295,7 +296,7 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
-                      &c->tok, &c->tokOff, &c->tokCnt, &c->tokSizes})
+                      &c->tok, &c->tokOff, &c->tokCnt, &c->tokSizes, &c->tolPool, &c->tolMeta})
         dev_release(*b);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
@@ -343,6 +344,35 @@ extern "C" int mi355lz4_debug_stats(mi355lz4_ctx *c, int enable, unsigned long l
     if (enable && !c->stats) HIP_TRY(hipMalloc((void **)&c->stats, PAR_STATS_COUNT * 8));
     if (c->stats) HIP_TRY(hipMemset(c->stats, 0, PAR_STATS_COUNT * 8));
     if (!enable && c->stats) { hipFree(c->stats); c->stats = nullptr; }
+    return MI355LZ4_OK;
+}
+
+// Diagnostic hook (not part of the public header): what the tolerant pass of the last linked single-stream call
+// left behind.  out[0] = dependent blocks that got a list, out[1] = entries in all lists, out[2] = longest
+// list, out[3] = blocks whose list overflowed, out[4] = dependent blocks without a list.
+extern "C" int mi355lz4_debug_tol_stats(mi355lz4_ctx *c, int nBlocks, long long *out)
+{
+    if (!c || !out || nBlocks <= 0 || !c->tolMeta.p) return fail(MI355LZ4_E_ARG, "debug_tol_stats: nothing to report");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> m((size_t)nBlocks * 3 + 4);
+    HIP_TRY(hipMemcpy(m.data(), c->tolMeta.p, m.size() * 4, hipMemcpyDeviceToHost));
+    const int regionsUsed = m[0];
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    // only blocks the tolerant kernel visited have meaningful entries: it hands out regions 0..regionsUsed-1
+    std::vector<char> seen((size_t)(regionsUsed > 0 ? regionsUsed : 0), 0);
+    for (int b = 0; b < nBlocks; b++) {
+        const int reg = m[4 + (size_t)b], cnt = m[4 + (size_t)nBlocks + b];
+        if (reg >= 0 && reg < regionsUsed && !seen[(size_t)reg]) {
+            seen[(size_t)reg] = 1;
+            out[0]++; out[1] += cnt;
+            if (cnt > out[2]) out[2] = cnt;
+            if (cnt > 8192) out[3]++;
+        }
+    }
+    out[4] = regionsUsed - out[0];
+    // RPL_STATS builds: rounds, super-batches, replay cycles / 16
+    out[5] = (unsigned)m[1]; out[6] = (unsigned)m[2]; out[7] = (unsigned)m[3];
     return MI355LZ4_OK;
 }
 
@@ -426,6 +456,21 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.dict0 = dict0; a.dict0Len = dict0Len;
     a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
     a.tok = nullptr; a.tokOff = nullptr; a.tokCnt = nullptr; a.tokSizes = nullptr; a.tokCap = 0;
+    a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
+    if (linked && !streamFirst) {
+        // one long linked stream: lists of deferred matches for up to tolMaxRegions dependent blocks per call
+        // (64 KiB each); blocks beyond that, and calls made without the pool, take the serial path
+        static const int tolMaxRegions = [] { const char *e = getenv("MI355LZ4_LINKED_POOL_BLOCKS"); return e ? atoi(e) : 4096; }();
+        const int regions = (nBlocks < tolMaxRegions) ? nBlocks : tolMaxRegions;
+        if (regions > 0 && dev_reserve(c->tolPool, (size_t)regions * tol_region_bytes()) == 0 &&
+            dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
+            a.tolPool = c->tolPool.p; a.tolRegions = regions;
+            a.tolCounter = (uint32_t *)c->tolMeta.p;
+            a.tolRegion = (int32_t *)c->tolMeta.p + 4;
+            a.tolCount = a.tolRegion + nBlocks;
+            a.tolSize = a.tolCount + nBlocks;
+        }
+    }
     if (c->decoder == 3) {
         // every sequence takes >= 3 compressed bytes: framedLen / 3 entries (+2 per block) hold every list of
         // disjoint blocks; lists that would not fit (overlapping blockOff) stay empty and decode sequentially

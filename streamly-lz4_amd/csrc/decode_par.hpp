@@ -116,10 +116,13 @@ __device__ __forceinline__ int par_scan_incl(int x)
 enum { PS_BATCHES, PS_SEQS, PS_ROUNDS, PS_MATCH_ITERS, PS_LIT_ITERS, PS_HANDOVERS, PS_SLIDES, PS_FULL, PS_FAR,
        PS_T_WINDOW, PS_T_SPEC, PS_T_CHAIN, PS_T_DECODE, PS_T_LIT, PS_T_NEED, PS_T_MATCH, PS_T_FLUSH, PS_T_SEQ, PS_COUNT };
 
-template <bool STATS, bool DICT>
+// TOL: tolerant (deferred-copy) decode of a block of a linked stream without its dictionary, see TolCtx in
+// decode_seq.hpp: matches that start before the block, or whose source touches a tainted granule, are
+// recorded in tol->list instead of being copied.
+template <bool STATS, bool DICT, bool TOL = false>
 __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict,
                                 uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, ParLds &L,
-                                unsigned long long *stats)
+                                unsigned long long *stats, TolCtx *tol = nullptr)
 {
     uint32_t sc[PS_COUNT];                 // wave-uniform (kept in scalar registers)
     uint32_t tmark = 0;
@@ -141,7 +144,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             for (int i = 0; i < PS_COUNT; i++) atomicAdd(&stats[i], (unsigned long long)sc[i]);
         }
     };
-    if (cap < 128 || srcLen < 64) return decode_block_seq(src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+    if (cap < 128 || srcLen < 64) return decode_block_seq<TOL>(src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, tol);
     // external dictionary (linked streams, cbits/lz4.c:2347-2355): a match that lies ENTIRELY in the
     // previous block's output is a far match with another base pointer; one that straddles the seam
     // (:1883-1911) is left to the sequential decoder
@@ -305,7 +308,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const int spos = dpos - (int)off16;              // match source
             ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap &&
                  ((spos >= 0 && (spos >= ringBase || spos + (int)ml <= flushed)) ||
-                  (DICT && spos >= dictLo && spos + (int)ml <= 0));
+                  (DICT && spos >= dictLo && spos + (int)ml <= 0) || (TOL && spos < 0));
             const uint64_t okm = __ballot(ok);
             const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
             lap(PS_T_DECODE);
@@ -324,7 +327,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             }
 
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
-            const bool nearSrc = spos >= ringBase;
+            const bool ext = TOL && spos < 0;                       // source starts in the previous block: deferred
+            const bool nearSrc = spos >= ringBase && !ext;
+            bool deferred = false;                                  // TOL: this lane's match is recorded, not copied
             const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
             const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
             const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups never read their own writes
@@ -382,10 +387,18 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
             // ---------------- 6. far matches: source already in global memory ----------------
             const uint64_t farm = __ballot(act && !nearSrc);
+            if (TOL && farm) {
+                // far sources are older than this batch: their taint is final
+                if (act && !nearSrc && (ext || tol_tainted(tol, spos, spos + (int)ml))) {
+                    deferred = true;
+                    tol_taint(tol, dpos, dpos + (int)ml);
+                }
+                wave_fence();
+            }
             if (farm) {
                 if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
                 const uint8_t *gsrc = (DICT && spos < 0) ? dictEnd + spos : dst + spos;
-                const bool mine = act && !nearSrc;
+                const bool mine = act && !nearSrc && !deferred;
                 // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
                 // past the match is written.  Far sources never overlap their destination.
                 const uint32_t step = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
@@ -432,7 +445,18 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             bool pending = act && nearSrc;                              // my match still has to be copied
             const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
             while (~done) {
-                const bool mine = pending && ((need & ~done) == 0ull);
+                const bool ready = pending && ((need & ~done) == 0ull);
+                bool mine = ready;
+                if (TOL) {
+                    // every sequence my source overlaps is complete, so its taint bits are final
+                    const int srcHi = min(spos + (int)ml, dpos);        // bytes from dpos on are my own output
+                    if (ready && srcHi > spos && tol_tainted(tol, spos, srcHi)) {
+                        deferred = true;
+                        mine = false;
+                        tol_taint(tol, dpos, dpos + (int)ml);
+                    }
+                    wave_fence();
+                }
                 if (STATS) sc[PS_ROUNDS]++;
                 // lanes whose chunks never read their own writes: two chunks per step (2 x 16, 2 x 8 or 2 x 4
                 // bytes by class), every lane's reads issued before the first write, so that a round costs
@@ -489,10 +513,22 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                         wave_fence();
                     }
                 }
-                pending = pending && !mine;
-                done |= __ballot(mine);
+                pending = pending && !ready;
+                done |= __ballot(ready);
             }
             wave_fence();
+            if (TOL) {
+                // the batch's deferred matches join the list in stream order (lane order)
+                const uint64_t dm = __ballot(deferred);
+                if (dm) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+                    const uint32_t base = tol->count;
+                    if (deferred && base + rank < tol->cap) tol->list[base + rank] = tol_entry(dpos, spos, ml);
+                    wave_fence();
+                    if (lane == 0) tol->count = base + (uint32_t)__builtin_popcountll(dm);
+                    wave_fence();
+                }
+            }
             lap(PS_T_MATCH);
 
             // ---------------- advance, 8. flush, slide ----------------
@@ -527,9 +563,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         const bool tail = (iend - ip < 64 || cap - op < 128);
         if (STATS && !tail) sc[PS_HANDOVERS]++;
         lap(PS_T_FLUSH);
-        int r = decode_seq_run(st, tail ? 0 : 1, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+        int r = decode_seq_dispatch<TOL>(st, tail ? 0 : 1, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, tol);
         if (r == SEQ_CONTINUE && (!st.fast || iend - st.ip < 64 || cap - st.op < 128))
-            r = decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+            r = decode_seq_dispatch<TOL>(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, tol);
         lap(PS_T_SEQ);
         r = uni(r);
         if (r != SEQ_CONTINUE) { publish(); return r; }

@@ -56,6 +56,72 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dstGeneric, int op, int
     wave_fence();
 }
 
+// ---------------------------------------------------------------------------
+// Tolerant ("deferred copy") decode, used for ONE long linked stream: a block of a linked
+// stream is decoded WITHOUT its dictionary, in parallel with every other block.  A match whose source lies
+// before the block (in the previous block's output, cbits/lz4.c:1883-1911) cannot be copied yet: it is
+// appended to the block's deferred list and its destination is marked in a taint bitmap (one bit per
+// granule of output).  A match whose source touches a tainted granule is deferred too, and taints its own
+// destination.  Everything else is copied as usual.  A later pass walks the stream in order and replays each
+// block's list with the previous block's final output beside it (kernels.hip: k_decode_fixup_regions).
+// ---------------------------------------------------------------------------
+struct TolEntry { uint16_t dpos, ml; int32_t src; };            // 8 bytes; src < 0: starts in the previous block's output
+__device__ __forceinline__ TolEntry tol_entry(int dpos, int src, uint32_t ml)
+{
+    TolEntry e;
+    e.dpos = (uint16_t)dpos; e.ml = (uint16_t)min(ml, 65535u); e.src = src;
+    return e;
+}
+
+struct TolCtx {
+    uint32_t taint[128];        // 4096 granules
+    TolEntry *list;             // global memory, cap entries
+    uint32_t cap, count;        // count may run past cap (overflow: the block falls back to the serial path)
+    uint32_t granShift;         // log2(granule bytes), >= 4
+};
+
+// any tainted granule in output bytes [lo, hi) ?  (lo < hi; per-lane values)
+__device__ __forceinline__ bool tol_tainted(const TolCtx *t, int lo, int hi)
+{
+    const uint32_t g0 = (uint32_t)lo >> t->granShift, g1 = (uint32_t)(hi - 1) >> t->granShift;
+    bool any = false;
+    for (uint32_t d = g0 >> 5; d <= (g1 >> 5); d++) {
+        uint32_t m = ~0u;
+        if (d == (g0 >> 5)) m &= ~0u << (g0 & 31u);
+        if (d == (g1 >> 5)) m &= ~0u >> (31u - (g1 & 31u));
+        any = any || ((t->taint[d] & m) != 0u);
+    }
+    return any;
+}
+__device__ __forceinline__ void tol_taint(TolCtx *t, int lo, int hi)
+{
+    const uint32_t g0 = (uint32_t)lo >> t->granShift, g1 = (uint32_t)(hi - 1) >> t->granShift;
+    for (uint32_t d = g0 >> 5; d <= (g1 >> 5); d++) {
+        uint32_t m = ~0u;
+        if (d == (g0 >> 5)) m &= ~0u << (g0 & 31u);
+        if (d == (g1 >> 5)) m &= ~0u >> (31u - (g1 & 31u));
+        atomicOr(&t->taint[d], m);
+    }
+}
+// wave-uniform arguments (the sequential decoder): defer this match?  If so it is recorded and tainted.
+__device__ __forceinline__ bool tol_defer_uniform(TolCtx *t, int op, int match, uint32_t ml)
+{
+    wave_fence();
+    bool defer = match < 0;
+    if (!defer && ml > 0) {
+        const int hi = min(match + (int)ml, op);            // bytes from op on are this match's own output
+        defer = hi > match && tol_tainted(t, match, hi);
+    }
+    if (!defer || ml == 0) return false;
+    if (lane_id() == 0) {
+        if (t->count < t->cap) t->list[t->count] = tol_entry(op, match, ml);
+        t->count += (ml > 65535u) ? t->cap + 1u : 1u;          // a match that long does not fit an entry: no list
+        tol_taint(t, op, op + (int)ml);
+    }
+    wave_fence();
+    return true;
+}
+
 // Resumable decoder state (all wave-uniform).
 struct SeqState {
     int ip;      // next token, relative to the block's first compressed byte
@@ -68,12 +134,18 @@ struct SeqState {
 // Returns SEQ_CONTINUE, or the block's final result: decoded size >= 0 or the
 // reference's negative code.  [bufLo, bufHi) bounds the readable framed buffer
 // (reads outside return 0 instead of faulting).
-__device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
-                              const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi)
+// TOL is a template parameter (not a run-time test of tol) so that the strict instantiation keeps the register
+// footprint the lane-parallel kernel's occupancy is built around (it is the one non-inlined call of that kernel).
+template <bool TOL>
+__device__ __forceinline__ int decode_seq_body(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                              const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi,
+                              TolCtx *tol)
 {
     const int iend = srcLen, oend = cap;
-    const bool useDict = (dict != nullptr) && dictLen > 0;
-    const bool checkOffset = dictLen < 65536u;                 // cbits/lz4.c:1764
+    // tolerant mode: parse as if a full 64 KiB dictionary were in force (no offset check, :1764); the replay
+    // pass validates every deferred source against the dictionary that really is
+    const bool useDict = TOL || ((dict != nullptr) && dictLen > 0);
+    const bool checkOffset = !TOL && dictLen < 65536u;             // cbits/lz4.c:1764
     int ip = st.ip, op = st.op;
     // Lengths are 64-bit: a run of 0xFF length bytes in a multi-megabyte block reaches 2^31 and more, and the
     // reference compares them as size_t (cbits/lz4.c:1811-1818); the 255-run itself accumulates in 32 bits
@@ -132,7 +204,8 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
                 if (!useDict) goto error;
                 if (op + ml > (int64_t)oend - LZ4_LASTLITERALS) goto error;   // :1884-1889
             }
-            wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
+            if (!(TOL && tol_defer_uniform(tol, op, match, (uint32_t)ml)))
+                wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
             op += (int)ml;
             continue;
         }
@@ -145,7 +218,8 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
             offset = rd(ip) | (rd(ip + 1) << 8); ip += 2;
             match = op - (int)offset;
             if (ml != 15 && offset >= 8 && match >= 0) {                      // :1959-1969
-                wave_copy_match(dst, op, match, (uint32_t)ml + LZ4_MINMATCH, offset, dict, dictLen);
+                if (!(TOL && tol_defer_uniform(tol, op, match, (uint32_t)ml + LZ4_MINMATCH)))
+                    wave_copy_match(dst, op, match, (uint32_t)ml + LZ4_MINMATCH, offset, dict, dictLen);
                 op += (int)ml + LZ4_MINMATCH;
                 continue;
             }
@@ -184,7 +258,8 @@ __device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq
         } else if (op + ml > (int64_t)oend - 12) {                            // :2137
             if (op + ml > (int64_t)oend - LZ4_LASTLITERALS) goto error;       // :2139
         }
-        wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
+        if (!(TOL && tol_defer_uniform(tol, op, match, (uint32_t)ml)))
+            wave_copy_match(dst, op, match, (uint32_t)ml, offset, dict, dictLen);
         op += (int)ml;
     }
     wave_fence();
@@ -194,10 +269,31 @@ error:
     return -ip - 1;                                                           // :2163
 }
 
+// The two out-of-line entry points.  They are plain (non-template) functions on purpose: the strict one is the
+// single non-inlined call of the lane-parallel kernel, whose occupancy is built around its register footprint.
+__device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                              const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi)
+{
+    return decode_seq_body<false>(st, maxSeq, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, nullptr);
+}
+__device__ __attribute__((noinline)) int decode_seq_run_tol(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                              const uint8_t *bufLo, const uint8_t *bufHi, TolCtx *tol)
+{
+    return decode_seq_body<true>(st, maxSeq, src, srcLen, dst, cap, nullptr, 0, bufLo, bufHi, tol);
+}
+template <bool TOL>
+__device__ __forceinline__ int decode_seq_dispatch(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+                              const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, TolCtx *tol)
+{
+    if constexpr (TOL) return decode_seq_run_tol(st, maxSeq, src, srcLen, dst, cap, bufLo, bufHi, tol);
+    else return decode_seq_run(st, maxSeq, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+}
+
 // Decode one whole block.  All arguments are wave-uniform.
+template <bool TOL = false>
 __device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
                                 const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo,
-                                const uint8_t *bufHi)
+                                const uint8_t *bufHi, TolCtx *tol = nullptr)
 {
     if (cap == 0) {                                              // :1781-1785
         InWindow w0; w0.lo = bufLo; w0.hi = bufHi; w0.load(src);
@@ -207,7 +303,7 @@ __device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, in
     SeqState st;
     st.ip = 0; st.op = 0;
     st.fast = cap >= 64;                                         // :1791
-    return decode_seq_run(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi);
+    return decode_seq_dispatch<TOL>(st, 0, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, tol);
 }
 
 } // namespace lz4dev

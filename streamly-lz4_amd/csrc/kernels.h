@@ -30,6 +30,14 @@ struct DecodeArgs {
     int nStreams;
     int lookBack;                 // linked, one stream: blocks of the SAME stream that precede block 0 in result[] /
                                   // outOff[] (already final); lets a long stream be decoded range by range
+    // deferred-copy decode of one long linked stream (linked_replay.hpp): per-block state of the tolerant pass
+    // and the pool its deferred lists live in; all null when the pool is not available
+    void *tolPool;                // TolEntry[tolRegions][TOL_LIST_CAP]
+    int tolRegions;
+    uint32_t *tolCounter;         // regions handed out so far
+    int32_t *tolRegion;           // per block: region index, or -1 (no list: serial path)
+    int32_t *tolCount;            // per block: entries appended (may exceed the capacity: overflow)
+    int32_t *tolSize;             // per block: result of the tolerant decode
     // token lists (tok_parse.hpp): block i's list is tok[tokOff[i] .. tokOff[i] + tokCnt[i]), one u16 per
     // sequence = its compressed length; tokCap = entries allocated in tok
     uint16_t *tok;
@@ -58,6 +66,7 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
+size_t tol_region_bytes();
 void launch_decode_tok(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,

@@ -12,6 +12,7 @@
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
 #include "decode_tok.hpp"
+#include "linked_replay.hpp"
 #include "encode_wave.hpp"
 
 using namespace lz4dev;
@@ -351,55 +352,186 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 // Regions are disjoint, so each is walked by the wavefront that finds its first block; a stream in
 // which every block decoded standalone has no region and the kernel costs one coalesced read of
 // result[].  (A reference-written linked stream is one long region: block 0, then every block fails.)
+//
+// Inside a region the chain of blocks is serial, but most of each block is not: k_decode_tolerant has
+// already decoded every failed block in parallel and left a list of the matches that (transitively) need the
+// previous block (TolCtx, decode_seq.hpp).  The walk only replays those lists, in LDS (linked_replay.hpp);
+// a block without a usable list is re-decoded by the exact serial decoder with its dictionary.
 __device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7F000000; }
 
-__global__ PAR_OCC void k_decode_fixup_regions(DecodeArgs a)
+struct TolLds { ParLds p; TolCtx t; };
+
+// (its out-of-line callee is decode_seq_run_tol, which no other kernel calls: the register bound can be its own)
+__global__ __launch_bounds__(64, 3) void k_decode_tolerant(DecodeArgs a)
+{
+    __shared__ TolLds lds;
+    const int blk = (int)blockIdx.x;
+    if (!is_codec_error(uni(a.result[blk]))) return;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int region = -1, count = 0, size = -1;
+    if (read_block_header(a, blk, data, compLen, cap) == 0 && cap <= RPL_HALF) {
+        unsigned got = 0;
+        if (lane_id() == 0) got = atomicAdd(a.tolCounter, 1u);
+        got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+        if (got < (unsigned)a.tolRegions) {
+            region = (int)got;
+            for (int i = lane_id(); i < 128; i += LZ4_WAVE) lds.t.taint[i] = 0;
+            if (lane_id() == 0) {
+                lds.t.list = (TolEntry *)a.tolPool + (size_t)region * TOL_LIST_CAP;
+                lds.t.cap = TOL_LIST_CAP;
+                lds.t.count = 0;
+                lds.t.granShift = 4;
+            }
+            wave_fence();
+            size = decode_block_par<false, false, true>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
+                                                        a.framed + a.framedLen, lds.p, nullptr, &lds.t);
+            size = uni(size);
+            wave_fence();
+            count = (int)lds.t.count;
+        }
+    }
+    if (lane_id() == 0) { a.tolRegion[blk] = region; a.tolCount[blk] = count; a.tolSize[blk] = size; }
+}
+
+// One workgroup of RPL_THREADS walks the regions that start in its 64 blocks.  Wave 0 takes every decision
+// (and runs the exact serial decoder when a block has no usable list); the replay and the block copies are
+// done by all waves.  The register bound matters although the LDS footprint allows one workgroup per CU anyway:
+// the out-of-line sequential decoder is compiled once for all its callers, and a caller without the bound would
+// relax it for every kernel.
+enum { RGN_END = 0, RGN_SKIP = 1, RGN_FIX = 2 };
+
+__global__ __attribute__((amdgpu_flat_work_group_size(RPL_THREADS, RPL_THREADS), amdgpu_waves_per_eu(PAR_WAVES, PAR_WAVES)))
+void k_decode_fixup_regions(DecodeArgs a)
 {
     __shared__ ParLds lds;
-    const int lane = lane_id();
+    __shared__ ReplayLds rl;
+    __shared__ RplCtl ctl;
+    __shared__ unsigned long long startMask;
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6;
     const int base = (int)blockIdx.x * LZ4_WAVE;
-    const int blk = base + lane;
-    const int r0 = (blk < a.nBlocks) ? a.result[blk] : 1;
-    const int rp = (blk > 0 && blk < a.nBlocks) ? a.result[blk - 1] : 1;
-    // block 0 of a range continues whatever region the blocks before the range ended in
-    const bool startsRegion = blk < a.nBlocks && r0 <= 0 && (blk == 0 || rp > 0);
-    for (uint64_t m = __ballot(startsRegion); m; m &= m - 1) {
+    if (wave == 0) {
+        const int blk = base + tid;
+        const int r0 = (blk < a.nBlocks) ? a.result[blk] : 1;
+        const int rp = (blk > 0 && blk < a.nBlocks) ? a.result[blk - 1] : 1;
+        // block 0 of a range continues whatever region the blocks before the range ended in
+        const bool startsRegion = blk < a.nBlocks && r0 <= 0 && (blk == 0 || rp > 0);
+        const uint64_t m0 = __ballot(startsRegion);
+        if (tid == 0) startMask = m0;
+    }
+    __syncthreads();
+    for (uint64_t m = startMask; m; m &= m - 1) {
         int f = base + (int)__builtin_ctzll(m);
+        // the dictionary in force: (pointer, length) are recomputed by every thread from data that is final
         const uint8_t *dict = nullptr;
         uint32_t dictLen = 0;
         if (f == 0) {
             if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
             for (int j = 1; j <= a.lookBack; j++) {               // the last block before the range that produced output
-                const int rj = uni(a.result[-j]);
+                const int rj = a.result[-j];
                 if (rj > 0) { dict = a.out + a.outOff[-j]; dictLen = (uint32_t)rj; break; }
             }
-        } else { dict = a.out + a.outOff[f - 1]; dictLen = (uint32_t)uni(a.result[f - 1]); }
+        } else { dict = a.out + a.outOff[f - 1]; dictLen = (uint32_t)a.result[f - 1]; }
+        bool dictInLds = false;                                   // rl.buf holds `dict` below RPL_HALF
         for (; f < a.nBlocks; f++) {
-            int r = uni(a.result[f]);
-            if (r > 0) break;                                     // end of the region
-            if (is_codec_error(r) && dictLen > 0) {
-                uint8_t *dst = a.out + a.outOff[f];
-                const uint8_t *data = nullptr;
-                int compLen = 0, cap = 0;
-                r = read_block_header(a, f, data, compLen, cap);
-                if (r == 0)
-                    r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed,
-                                                      a.framed + a.framedLen, lds, nullptr);
-                r = uni(r);
-                if (lane_id() == 0) a.result[f] = r;
-                if (r > 0) { dict = dst; dictLen = (uint32_t)r; }   // :2331-2333, :2353-2355
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            if (tid == 0) {
+                const int r = a.result[f];
+                int action = RGN_FIX;
+                if (r > 0) action = RGN_END;                      // end of the region
+                else if (!is_codec_error(r) || dictLen == 0) action = RGN_SKIP;   // nothing to fix, or nothing to fix it with
+                ctl.action = action;
+                ctl.r = r;
             }
+            __syncthreads();
+            const int action = ctl.action;
+            __syncthreads();
+            if (action == RGN_END) break;
+            if (action == RGN_SKIP) continue;
+            uint8_t *dst = a.out + a.outOff[f];
+            if (wave == 0) {
+                const uint8_t *data0 = nullptr;
+                int compLen0 = 0, cap0 = 0;
+                const int hdr = read_block_header(a, f, data0, compLen0, cap0);
+                if (tid == 0) {
+                    ctl.hdr = hdr; ctl.cap = cap0; ctl.compLen = compLen0;
+                    ctl.region = -1; ctl.count = 0; ctl.size = -1;
+                    if (hdr == 0 && a.tolPool) { ctl.region = a.tolRegion[f]; ctl.count = a.tolCount[f]; ctl.size = a.tolSize[f]; }
+                }
+            }
+            __syncthreads();
+            const int hdr = ctl.hdr, cap = ctl.cap, region = ctl.region, count = ctl.count, size = ctl.size;
+            bool fixed = false;
+            if (region >= 0 && count <= TOL_LIST_CAP && size > 0 && size <= RPL_HALF && cap <= RPL_HALF) {
+                const int dl = (int)min(dictLen, (uint32_t)RPL_HALF);
+                if (!dictInLds) rpl_load(rl.buf + RPL_HALF - dl, dict + (dictLen - (uint32_t)dl), dl);
+                rpl_load(rl.buf + RPL_HALF, dst, size);
+                __syncthreads();
+                // dictLen >= 64 KiB: no offset check in the reference (:1764); every offset fits 65535 anyway
+#ifdef RPL_STATS
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+                fixed = replay_block(rl, ctl, (const TolEntry *)a.tolPool + (size_t)region * TOL_LIST_CAP, count, dl, size, cap,
+                                     a.tolCounter);
+#ifdef RPL_STATS
+                if (tid == 0) atomicAdd(&a.tolCounter[3], (unsigned)((__builtin_amdgcn_s_memtime() - t0) >> 4));
+#endif
+                if (fixed) {
+                    rpl_store(dst, rl.buf + RPL_HALF, size);
+                    __syncthreads();
+                    // this block is the next one's dictionary: move it below RPL_HALF (upwards in steps that do
+                    // not overlap: size <= RPL_HALF, so source and destination ranges are disjoint)
+                    if ((size & 15) == 0) {
+                        for (int c = tid; c < (size >> 4); c += RPL_THREADS) {
+                            const par_v4 v = *(const par_v4 *)(rl.buf + RPL_HALF + 16 * c);
+                            *(par_v4 *)(rl.buf + RPL_HALF - size + 16 * c) = v;
+                        }
+                    } else {
+                        for (int x = tid; x < size; x += RPL_THREADS) rl.buf[RPL_HALF - size + x] = rl.buf[RPL_HALF + x];
+                    }
+                    __syncthreads();
+                    dictInLds = true;
+                    if (tid == 0) { ctl.r = size; a.result[f] = size; }
+                }
+            }
+            if (!fixed) {
+                // exact serial decode with the dictionary (also what yields the reference's error codes), wave 0 alone
+                if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // replayed blocks were written by this workgroup
+                    const uint8_t *data = nullptr;
+                    int compLen = 0, cap1 = 0;
+                    int r = read_block_header(a, f, data, compLen, cap1);
+                    if (r == 0)
+                        r = decode_block_par<false, true>(data, compLen, dst, cap1, dict, dictLen, a.framed,
+                                                          a.framed + a.framedLen, lds, nullptr);
+                    r = uni(r);
+                    if (lane_id() == 0) { ctl.r = r; a.result[f] = r; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                }
+                dictInLds = false;
+            }
+            __syncthreads();
+            const int r = ctl.r;
+            __syncthreads();
+            if (r > 0) { dict = dst; dictLen = (uint32_t)r; }     // :2331-2333, :2353-2355
+            (void)hdr;
         }
+        __syncthreads();
     }
 }
+
+size_t tol_region_bytes() { return (size_t)TOL_LIST_CAP * sizeof(TolEntry); }
 
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
 {
     if (a.nBlocks <= 0) return;
     if (!a.streamFirst) {
-        hipLaunchKernelGGL(k_decode_fixup_regions, dim3((unsigned)((a.nBlocks + LZ4_WAVE - 1) / LZ4_WAVE)), dim3(64), 0,
-                           s, a);
+        if (a.tolPool) {
+            hipMemsetAsync(a.tolCounter, 0, 4 * sizeof(uint32_t), s);
+            hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+        }
+        hipLaunchKernelGGL(k_decode_fixup_regions, dim3((unsigned)((a.nBlocks + LZ4_WAVE - 1) / LZ4_WAVE)),
+                           dim3(RPL_THREADS), 0, s, a);
         return;
     }
     if (a.nStreams > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);

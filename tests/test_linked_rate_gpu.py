@@ -97,3 +97,55 @@ def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
         f.write(json.dumps(rec) + "\n")
     print(rec)
     assert best[True] <= best[False] * 1.02 + 0.02, rec
+
+
+@pytest.mark.parametrize("kind,n_blocks", [("text", 1024), ("lzsynth_shared", 512)])
+def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks):
+    """ONE long stream written by the reference's linked compressor (what a reference-written file is): the
+    tolerant parallel pass + the in-order LDS replay (linked_replay.hpp).  Bit-exact; the rate is recorded."""
+    import torch
+    dev = torch.device("cuda:0")
+    bl = 65536
+    if kind == "text":
+        data = oracle.gen("text", n_blocks, bl, first_block=7).tobytes()
+    else:
+        # every block built from the same vocabulary as its predecessor: long matches across the block seam
+        base = oracle.gen("lzsynth", 2, bl, first_block=3).tobytes()
+        rng = np.random.default_rng(5)
+        parts = []
+        for i in range(n_blocks):
+            o = int(rng.integers(0, bl))
+            parts.append(base[o:o + bl])
+        data = b"".join(parts)
+    fr = oracle.frame_compress(data, bl, 1, 8, True)
+    nb = n_blocks
+    offs, pos = [], 0
+    for _ in range(nb):
+        offs.append(pos)
+        pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+    assert pos == len(fr)
+    buf = torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).to(dev)
+    off = torch.tensor(offs + [pos], dtype=torch.int64, device=dev)
+    ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
+    out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
+    res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    engine.decompress_batch_device(buf, len(fr), off, nb, out, ooff, res, linked=False)
+    engine.synchronize()
+    dependent = int((res < 0).sum().item())
+    e0, e1 = slz4.Event(), slz4.Event()
+    best = 1e9
+    for _ in range(3):
+        out.zero_()
+        engine.record(e0)
+        engine.decompress_batch_device(buf, len(fr), off, nb, out, ooff, res, linked=True)
+        engine.record(e1)
+        engine.synchronize()
+        best = min(best, engine.elapsed_ms(e0, e1))
+    assert bool((res == bl).all().item())
+    ref = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+    assert torch.equal(out, ref)
+    rec = {"streams": 1, "blocks_per_stream": nb, "block_len": bl, "data": kind + ", reference-linked", "dependent_blocks": dependent,
+           "ms": round(best, 3), "GBps_uncompressed": round(nb * bl / best / 1e6, 3), "ratio": round(nb * bl / len(fr), 3)}
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)
