@@ -150,7 +150,6 @@ struct mi355lz4_ctx {
     int decoder = 0;
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
-    DevBuf tok, tokOff, tokCnt, tokSizes;   // token lists of the list-driven decoder
     DevBuf tolPool, tolMeta;                // deferred-copy decode of a long linked stream (linked_replay.hpp)
     DevBuf pinIn, pinOut;   // pinned host staging
     DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
@@ -296,7 +295,7 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
-                      &c->tok, &c->tokOff, &c->tokCnt, &c->tokSizes, &c->tolPool, &c->tolMeta})
+                      &c->tolPool, &c->tolMeta})
         dev_release(*b);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
@@ -327,7 +326,7 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -455,7 +454,6 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
     a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
-    a.tok = nullptr; a.tokOff = nullptr; a.tokCnt = nullptr; a.tokSizes = nullptr; a.tokCap = 0;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     if (linked && !streamFirst) {
         // one long linked stream: lists of deferred matches for up to tolMaxRegions dependent blocks per call
@@ -471,22 +469,8 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             a.tolSize = a.tolCount + nBlocks;
         }
     }
-    if (c->decoder == 3) {
-        // every sequence takes >= 3 compressed bytes: framedLen / 3 entries (+2 per block) hold every list of
-        // disjoint blocks; lists that would not fit (overlapping blockOff) stay empty and decode sequentially
-        const uint64_t entries = framedLen / 3 + 2ull * (uint64_t)nBlocks + 64;
-        int r = dev_reserve(c->tok, entries * sizeof(uint16_t));
-        if (!r) r = dev_reserve(c->tokOff, ((size_t)nBlocks + 1) * sizeof(uint64_t));
-        if (!r) r = dev_reserve(c->tokCnt, (size_t)nBlocks * sizeof(int32_t));
-        if (!r) r = dev_reserve(c->tokSizes, (size_t)nBlocks * sizeof(int32_t));
-        if (r) return r;
-        a.tok = (uint16_t *)c->tok.p; a.tokOff = (uint64_t *)c->tokOff.p; a.tokCnt = (int32_t *)c->tokCnt.p;
-        a.tokSizes = (int32_t *)c->tokSizes.p; a.tokCap = entries;
-    }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
-    else if (c->decoder == 3)
-        launch_decode_tok(a, c->stats, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
     if (linked) launch_decode_fixup_linked(a, c->stream);

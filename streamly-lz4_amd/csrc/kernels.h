@@ -38,13 +38,6 @@ struct DecodeArgs {
     int32_t *tolRegion;           // per block: region index, or -1 (no list: serial path)
     int32_t *tolCount;            // per block: entries appended (may exceed the capacity: overflow)
     int32_t *tolSize;             // per block: result of the tolerant decode
-    // token lists (tok_parse.hpp): block i's list is tok[tokOff[i] .. tokOff[i] + tokCnt[i]), one u16 per
-    // sequence = its compressed length; tokCap = entries allocated in tok
-    uint16_t *tok;
-    uint64_t *tokOff;
-    int32_t *tokCnt;
-    int32_t *tokSizes;            // scratch: per-block list capacity (input of the scan that yields tokOff)
-    uint64_t tokCap;
 };
 
 struct EncodeArgs {
@@ -67,7 +60,6 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
 #define PAR_STATS_COUNT 32
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
 size_t tol_region_bytes();
-void launch_decode_tok(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
                     uint8_t *dense, size_t denseCap, uint64_t *denseOff, hipStream_t s);

@@ -11,7 +11,6 @@
 
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
-#include "decode_tok.hpp"
 #include "linked_replay.hpp"
 #include "encode_wave.hpp"
 
@@ -535,83 +534,4 @@ void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
         return;
     }
     if (a.nStreams > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);
-}
-
-// ---------------------------------------------------------------------------
-// Token lists + the list-driven lane-parallel decoder (tok_parse.hpp, decode_tok.hpp)
-// ---------------------------------------------------------------------------
-
-// capacity of block i's list: a sequence takes at least 3 compressed bytes
-__global__ __launch_bounds__(256) void k_tok_caps(DecodeArgs a)
-{
-    const int blk = (int)(blockIdx.x * 256u + threadIdx.x);
-    if (blk >= a.nBlocks) return;
-    const uint8_t *data = nullptr;
-    int compLen = 0, cap = 0;
-    const int r = read_block_header(a, blk, data, compLen, cap);
-    a.tokSizes[blk] = (r == 0) ? compLen / 3 + 2 : 0;
-}
-
-// EXPERIMENT: one lane per block, bytes straight from global memory
-__global__ __launch_bounds__(64) void k_tok_parse_naive(DecodeArgs a)
-{
-    const int blk = (int)(blockIdx.x * 64u + threadIdx.x);
-    if (blk >= a.nBlocks) return;
-    const uint8_t *data = nullptr;
-    int compLen = 0, cap = 0;
-    int n = 0;
-    const uint64_t t0 = a.tokOff[blk], t1 = a.tokOff[blk + 1];
-    if (read_block_header(a, blk, data, compLen, cap) == 0 && t1 <= a.tokCap) {
-        uint16_t *out = a.tok + t0;
-        const int capTok = (int)(t1 - t0);
-        const int64_t iend = compLen;
-        int64_t p = 0;
-        while (n < capTok && p < iend) {
-            const uint32_t t = data[p];
-            int64_t lit = t >> 4, q = p + 1;
-            bool bad = false;
-            if (lit == 15) {
-                uint32_t b;
-                do { if (q >= iend) { bad = true; break; } b = data[q++]; lit += b; } while (b == 255);
-            }
-            if (bad) break;
-            q += lit;
-            if (q + 2 > iend) break;
-            q += 2;
-            if ((t & 15u) == 15u) {
-                uint32_t b;
-                do { if (q >= iend) { bad = true; break; } b = data[q++]; } while (b == 255);
-            }
-            if (bad) break;
-            out[n++] = (uint16_t)min((int64_t)65535, q - p);
-            p = q;
-        }
-    }
-    a.tokCnt[blk] = n;
-}
-
-template <bool STATS>
-__global__ PAR_OCC void k_decode_tok(DecodeArgs a, unsigned long long *stats)
-{
-    __shared__ TokLds lds;
-    const int blk = (int)blockIdx.x;
-    const uint8_t *data = nullptr;
-    int compLen = 0, cap = 0;
-    int r = read_block_header(a, blk, data, compLen, cap);
-    if (r == 0)
-        r = decode_block_tok<STATS, false>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
-                                           a.framed + a.framedLen, lds, a.tok + a.tokOff[blk], uni(a.tokCnt[blk]), stats);
-    if (lane_id() == 0) a.result[blk] = r;
-}
-
-void launch_decode_tok(const DecodeArgs &a, unsigned long long *stats, hipStream_t s)
-{
-    if (a.nBlocks <= 0) return;
-    hipLaunchKernelGGL(k_tok_caps, dim3((unsigned)((a.nBlocks + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.tokSizes, a.nBlocks, a.tokOff);
-    hipLaunchKernelGGL(k_tok_parse_naive, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
-    if (stats)
-        hipLaunchKernelGGL(k_decode_tok<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
-    else
-        hipLaunchKernelGGL(k_decode_tok<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
 }

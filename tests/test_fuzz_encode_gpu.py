@@ -66,7 +66,7 @@ def test_encode_fuzz_structured(engine, oracle, accel):
         code, out = oracle.decompress_block(fr[pos + 8:pos + f], len(b))
         assert code == len(b) and out == b, (i, len(b), code)
         pos += f
-    for dec in (2, 1, 3):
+    for dec in (2, 1):
         engine.set_decoder(dec)
         try:
             out, blen = engine.decompress_batch(fr)
