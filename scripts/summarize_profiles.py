@@ -70,6 +70,11 @@ def main():
         "%s %s: FETCH_SIZE=%.4g KB (x2) + WRITE_SIZE=%.4g KB per launch of %s"
         % (rnd, tag, out["FETCH_SIZE"], out["WRITE_SIZE"], KERNEL_OF[key]))
     t["_notes"] = notes
+    try:
+        import subprocess
+        t["_commit"] = "commit " + subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        pass
     json.dump(t, open(tpath, "w"), indent=1)
     print("traffic", traffic)
     with open(stats) as f:
