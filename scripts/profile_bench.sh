@@ -12,9 +12,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 10 --warmup 2 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-    python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+    python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-host-api "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> "$OUT/fetch.err"
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-api --no-extra "$@" > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> "$OUT/write.err"
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-host-api --no-extra "$@" > /dev/null 2> "$OUT/write.err"
 cat "$OUT/bench.json"
