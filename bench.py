@@ -277,6 +277,8 @@ def main():
         do_compress()
         eng.synchronize()
         fl = flen.clone()
+        gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)     # untimed: sets up the peer connections
+        del gathered
         barrier()
         g0 = time.perf_counter()
         gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)
@@ -315,7 +317,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get("%s:%s" % (args.workload, dom))
+            # the PMC figure is per launch of the workload's full-size batch
+            traffic = tj.get("%s:%s" % (args.workload, dom)) if NB == WORKLOADS[args.workload][2] and corpus_bytes is None else None
             traffic_src = "profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of %s)" % tj.get("_commit", "an earlier commit")
         except Exception:
             traffic = None
