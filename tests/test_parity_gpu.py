@@ -638,6 +638,46 @@ def test_linked_streams_fuzz_codes(engine, oracle):
                 assert out[o:o + len(eouts[j])] == eouts[j], (t, j)
 
 
+def test_single_linked_stream_fuzz_codes(engine, oracle):
+    """ONE reference-linked stream per call (linked = 1: tolerant parallel pass + in-order replay,
+    csrc/linked_replay.hpp) with corruptions of payload bytes: every block's result (size or the reference's
+    negative code, cbits/lz4.c:2163) and every decoded byte equals the oracle's linked decode, block by block
+    -- whether a block was replayed from its deferred list or went back to the exact serial decoder."""
+    rng = random.Random(77)
+    for trial in range(40):
+        kind = ["text", "lzsynth", "text"][trial % 3]
+        bl = [65536, 65536, 16384, 4096][trial % 4]
+        nblk = rng.randint(3, 9)
+        d = oracle.gen(kind, nblk, bl, first_block=900 + 13 * trial).tobytes()
+        if trial % 5 == 2:                                   # periodic: matches that straddle the block seam
+            pat = d[:2711]
+            d = (pat * (len(d) // len(pat) + 1))[: len(d)]
+        if trial % 7 == 3:                                   # shared vocabulary shifted by whole blocks: long far matches
+            d = d[:bl] * nblk
+        fr = bytearray(oracle.frame_compress(d, bl, 1, 8, True))
+        blocks = split_blocks(bytes(fr))
+        for _ in range(rng.choice([0, 1, 1, 2, 4])):
+            bi = rng.randrange(1, len(blocks))
+            start = sum(len(b) for b in blocks[:bi]) + 8
+            pos = start + rng.randrange(len(blocks[bi]) - 8)
+            fr[pos] = rng.randrange(256) if rng.random() < 0.5 else fr[pos] ^ (1 << rng.randrange(8))
+        dict_bytes, eres, eouts = None, [], []
+        for b in split_blocks(bytes(fr)):
+            cap = int.from_bytes(b[4:8], "little")
+            code, dec = oracle.decompress_block(b[8:], cap, dict_bytes)
+            eres.append(code)
+            eouts.append(dec if code >= 0 else None)
+            if code > 0:
+                dict_bytes = dec
+        out, res, ulen, first = _decode_streams(engine, [bytes(fr)], "one")
+        assert res == eres, (trial, res, eres)
+        o = 0
+        for j, e in enumerate(eouts):
+            if e is not None:
+                assert out[o:o + len(e)] == e, (trial, j)
+            o += ulen[j]
+
+
 def test_linked_streams_host_api(engine, oracle):
     """mi355lz4_decompress_streams (host buffers) == the device entry point == the raw data."""
     datas, frs = [], []
