@@ -23,12 +23,13 @@ struct __attribute__((aligned(16))) ReplayLds {
     uint8_t buf[2 * RPL_HALF + 64];     // [dictionary, ending at RPL_HALF | block], + slack for 16-byte chunk reads
 };
 
-#define RPL_THREADS 512            // one workgroup of 8 waves walks a region: the replay is latency-bound, so the
-                                   // entries of a block are copied 512 at a time
+#define RPL_THREADS 1024           // one workgroup of 16 waves walks a region: the replay is latency-bound, so the
+                                   // entries of a block are copied 1024 at a time (dependency depth grows slower than the batch)
 
 struct RplCtl {                    // workgroup-wide decisions and scratch of the region walk
     int32_t dposv[RPL_THREADS];    // destinations of the current super-batch (ascending)
     uint32_t doneBits[RPL_THREADS / 32];
+    uint32_t doneCount;            // entries of the current super-batch copied so far
     int32_t action, r, hdr, region, count, size, cap, compLen, bad;
 };
 
@@ -96,6 +97,7 @@ __device__ bool replay_block(ReplayLds &L, RplCtl &C, const TolEntry *list, int 
         if (has && spos < 0 && dpos + ml > cap - LZ4_LASTLITERALS) good = false;
         if (!good) C.bad = 1;
         C.dposv[tid] = has ? dpos : 0x7fffffff;
+        if (tid == 0) C.doneCount = 0;
         if (tid < RPL_THREADS / 32) {
             const int lo = tid * 32;                       // entries lo .. lo+31: bits of absent entries start out done
             C.doneBits[tid] = (cnt >= lo + 32) ? 0u : ((cnt <= lo) ? ~0u : (~0u << (cnt - lo)));
@@ -194,10 +196,17 @@ __device__ bool replay_block(ReplayLds &L, RplCtl &C, const TolEntry *list, int 
                 wave_fence();
             }
             pending = pending && !ready;
-            __syncthreads();                               // this round's bytes are in place ...
+            // An entry is marked complete right behind its own copy: the LDS executes one wave's operations in
+            // order, so whoever sees the bit also sees the bytes.  A wave that sees it in the same round merely
+            // starts a dependent entry a round early.  One barrier per round: everyone has counted.
+            wave_fence();
             if (ready) atomicOr(&C.doneBits[tid >> 5], 1u << (tid & 31));
-            if (!__syncthreads_or(pending ? 1 : 0)) break; // ... before anyone sees them marked complete
+            const uint64_t rm = __ballot(ready);
+            if (rm && lane == 0) atomicAdd(&C.doneCount, (uint32_t)__builtin_popcountll(rm));
+            __syncthreads();
+            if (C.doneCount >= (uint32_t)cnt) break;
         }
+        __syncthreads();                                   // nobody resets doneCount while it is still being read
     }
     __syncthreads();
     return true;
