@@ -102,7 +102,11 @@ int mi355lz4_compress_batch_device(mi355lz4_ctx *ctx, const uint8_t *src, const 
                                    int32_t *framedLen);
 
 /* Pack slots into one dense framed stream: denseOff[0..nBlocks] receives the
- * exclusive scan of framedLen (denseOff[nBlocks] = total), dense the bytes. */
+ * exclusive scan of framedLen (denseOff[nBlocks] = total), dense the bytes.
+ * Nothing is written at or past dense + denseCap: a block that does not fit is
+ * skipped, and the caller sees it by denseOff[nBlocks] > denseCap (the call is
+ * asynchronous, so it cannot report that itself).  nBlocks * slotStride always
+ * suffices. */
 int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slotStride,
                             const int32_t *framedLen, int nBlocks, uint8_t *dense, size_t denseCap,
                             uint64_t *denseOff);
@@ -145,7 +149,12 @@ int mi355lz4_index_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t fra
                           const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
                           uint64_t *outOff);
 
-/* ---- host-buffer batched API (what the Haskell shim binds; synchronous) - */
+/* ---- host-buffer batched API (what the Haskell shim binds; synchronous) -
+ * A call is pipelined over groups of blocks (MI355LZ4_GROUP_MB, default 64 MiB):
+ * H2D of group i+1, the kernels of group i and D2H of group i-1 overlap on
+ * separate streams.  Caller buffers that are page-locked (hipHostMalloc /
+ * hipHostRegister) are handed to the DMA engines directly; pageable ones are
+ * staged through pinned slots by a small copy pool (MI355LZ4_COPY_THREADS). */
 
 /* Compress nBlocks host arrays into one dense framed stream in framedOut
  * (capacity cap).  blockFramedLen[i] (optional) = headerKind + compLen of
