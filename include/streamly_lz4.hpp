@@ -84,4 +84,31 @@ std::pair<std::pair<BlockConfig, FrameConfig>, StreamPtr> simpleFrameParser(Stre
 // decompressChunksWithD simpleFrameParserD  (Internal/LZ4.hs:569-577)
 StreamPtr decompressChunksWith(StreamPtr in, Engine &eng);
 
+// ---- the standard LZ4 frame format (interop with liblz4's LZ4F_* and the lz4 CLI) ----
+// What simpleFrameParserD stops short of (Internal/LZ4.hs:631-638 rejects independent blocks, checksums and
+// content size; :605 skips the header checksum): csrc/lz4_frame.cpp.
+struct Lz4FrameOptions {
+    BlockSize blockMax = BlockSize::BlockMax64KB;       // BD byte; one of BlockMax64KB .. BlockMax4MB
+    bool blockChecksum = false;                         // xxh32 behind every block
+    bool contentChecksum = true;                        // xxh32 of the content behind the end mark (the CLI's default)
+    bool contentSize = false;                           // 8-byte content size in the descriptor
+};
+uint32_t xxh32(const uint8_t *p, size_t len, uint32_t seed);
+// One frame, independent blocks (every block is compressed on its own: the batch is the frame).
+Array lz4FrameCompress(const Array &data, int speed, Engine &eng, const Lz4FrameOptions &opt = Lz4FrameOptions());
+// Host half of the reader: parses ONE frame at frame[at...] (advancing at), verifies header and block checksums and
+// re-frames the blocks for the engine ([compLen LE32][LZ4 block], stored blocks as literal-only blocks).
+// Returns false for a skippable frame.
+struct Lz4FrameIndex {
+    bool independent = false, hasContentSize = false, hasContentChecksum = false;
+    size_t blockMax = 0;
+    uint64_t contentSize = 0;
+    uint32_t contentChecksum = 0;
+    Array framed;
+    std::vector<size_t> blockAt;                        // offsets of the block headers in framed, plus its size
+};
+bool lz4FrameParse(const Array &frame, size_t &at, Lz4FrameIndex &ix);
+// Any sequence of frames and skippable frames; linked or independent blocks, stored blocks, all checksums verified.
+Array lz4FrameDecompress(const Array &frame, Engine &eng);
+
 } // namespace streamly_lz4

@@ -22,6 +22,7 @@ __all__ = [
     "defaultBlockConfig", "defaultFrameConfig", "setBlockMaxSize", "setFrameEndMark",
     "compressChunks", "decompressChunks", "decompressChunksRaw", "resizeChunks",
     "decompressChunksWith", "simpleFrameParser", "compress_bound", "slot_stride", "device_count",
+    "xxh32", "lz4FrameCompress", "lz4FrameDecompress",
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -126,6 +127,10 @@ def _load():
     sig("slz4_decompress_chunks", C.c_int, vp, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
     sig("slz4_decompress_chunks_with", C.c_int, vp, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
     sig("slz4_simple_frame_parser", C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(vp))
+    # standard LZ4 frames
+    sig("slz4_xxh32", C.c_uint32, _u8p, C.c_size_t, C.c_uint32)
+    sig("slz4_lz4frame_compress", C.c_int, vp, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t, C.POINTER(vp))
+    sig("slz4_lz4frame_decompress", C.c_int, vp, _u8p, C.c_size_t, C.POINTER(vp))
     return L
 
 
@@ -487,3 +492,32 @@ def simpleFrameParser(arrays):
     if kind < 0:
         raise LZ4Error((lib.slz4_last_error() or b"").decode("utf-8", "replace"))
     return (BlockConfig(kind), FrameConfig(bool(em.value))), _unpack(h)
+
+
+# ---- the standard LZ4 frame format (csrc/lz4_frame.cpp): interop with liblz4's LZ4F_* and the lz4 CLI ----
+def _bytes_arg(data):
+    a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    if a.size == 0:
+        return np.zeros(1, dtype=np.uint8), 0
+    return a, int(a.size)
+
+
+def xxh32(data, seed=0):
+    """xxHash32, the checksum of the LZ4 frame format (host code, no GPU)."""
+    a, n = _bytes_arg(data)
+    return int(lib.slz4_xxh32(a.ctypes.data_as(_u8p), n, int(seed)))
+
+
+def lz4FrameCompress(data, engine, speed=1, blockMax=BlockSize.BlockMax64KB, blockChecksum=False, contentChecksum=True,
+                     contentSize=False):
+    """One standard LZ4 frame with independent blocks -- readable by LZ4F_decompress / `lz4 -d`.  The reference's
+    own frame support stops at parsing a header without these options (src/Streamly/Internal/LZ4.hs:631-638)."""
+    a, n = _bytes_arg(data)
+    flags = (1 if blockChecksum else 0) | (2 if contentChecksum else 0) | (4 if contentSize else 0)
+    return _run(lib.slz4_lz4frame_compress, engine._h, int(blockMax), flags, int(speed), a.ctypes.data_as(_u8p), n)[0]
+
+
+def lz4FrameDecompress(frame, engine):
+    """Decode any sequence of standard LZ4 frames (linked or independent blocks, stored blocks, checksums verified)."""
+    a, n = _bytes_arg(frame)
+    return _run(lib.slz4_lz4frame_decompress, engine._h, a.ctypes.data_as(_u8p), n)[0]

@@ -139,8 +139,74 @@ static void legacy_no_device()
     CHECK(threw);
 }
 
+// the frame reader's host half on valid, damaged and truncated frames: it either parses or throws, nothing else
+static void frame_parser_fuzz()
+{
+    using namespace streamly_lz4;
+    std::mt19937_64 rng(99);
+    auto put32 = [](Array &a, uint32_t v) { for (int k = 0; k < 4; k++) a.push_back((uint8_t)(v >> (8 * k))); };
+    for (int iter = 0; iter < 300; iter++) {
+        const bool bsum = rng() & 1, csum = rng() & 1, csize = rng() & 1, indep = rng() & 1;
+        const int code = 4 + (int)(rng() % 4);
+        Array f, content;
+        if (rng() % 4 == 0) { put32(f, 0x184D2A50u + (uint32_t)(rng() % 16)); put32(f, 5); for (int k = 0; k < 5; k++) f.push_back((uint8_t)k); }
+        const size_t frameAt = f.size();
+        put32(f, 0x184D2204u);
+        const size_t descAt = f.size();
+        f.push_back((uint8_t)(0x40 | (indep ? 0x20 : 0) | (bsum ? 0x10 : 0) | (csize ? 0x08 : 0) | (csum ? 0x04 : 0)));
+        f.push_back((uint8_t)(code << 4));
+        const int nb = (int)(rng() % 5);
+        std::vector<Array> blocks;
+        for (int b = 0; b < nb; b++) {
+            Array blk(rng() % 700);
+            for (auto &x : blk) x = (uint8_t)rng();
+            content.insert(content.end(), blk.begin(), blk.end());
+            blocks.push_back(std::move(blk));
+        }
+        if (csize) for (int k = 0; k < 8; k++) f.push_back((uint8_t)((uint64_t)content.size() >> (8 * k)));
+        f.push_back((uint8_t)(xxh32(f.data() + descAt, f.size() - descAt, 0) >> 8));
+        for (const Array &blk : blocks) {
+            put32(f, (uint32_t)blk.size() | 0x80000000u);
+            f.insert(f.end(), blk.begin(), blk.end());
+            if (bsum) put32(f, xxh32(blk.data(), blk.size(), 0));
+        }
+        put32(f, 0);
+        if (csum) put32(f, xxh32(content.data(), content.size(), 0));
+
+        // intact: parses, and the re-framed literal blocks carry the content
+        {
+            size_t at = 0;
+            Lz4FrameIndex ix;
+            bool isFrame = lz4FrameParse(f, at, ix);
+            if (frameAt) { CHECK(!isFrame && at == frameAt); isFrame = lz4FrameParse(f, at, ix); }
+            CHECK(isFrame && at == f.size() && ix.independent == indep && ix.blockMax == ((size_t)1 << (8 + 2 * code)));
+            CHECK(!csize || ix.contentSize == content.size());
+            size_t bytes = 0, live = 0;
+            for (const Array &blk : blocks) { bytes += blk.size(); live += !blk.empty(); }
+            CHECK(ix.blockAt.size() == live + 1 && ix.framed.size() >= bytes + 5 * live);
+        }
+        // damaged
+        for (int m = 0; m < 20; m++) {
+            Array g = f;
+            const int kind = (int)(rng() % 3);
+            if (kind == 0 && !g.empty()) g.resize(rng() % g.size());
+            else if (kind == 1 && !g.empty()) g[rng() % g.size()] ^= (uint8_t)(1u << (rng() % 8));
+            else for (int k = 0; k < 4 && !g.empty(); k++) g[rng() % g.size()] = (uint8_t)rng();
+            size_t at = 0;
+            try {
+                Lz4FrameIndex ix;
+                while (at < g.size()) lz4FrameParse(g, at, ix);
+            } catch (const Error &) {
+            }
+            CHECK(at <= g.size());
+        }
+    }
+    CHECK(xxh32(nullptr, 0, 0) == 0x02CC5D05u);
+}
+
 int main()
 {
+    frame_parser_fuzz();
     pool_stress();
     resize_checks();
     legacy_no_device();

@@ -133,6 +133,22 @@ def test_simple_frame_parser(slz4):
             framing.simple_frame_parser(data)
 
 
+def test_xxh32_known_answers(slz4):
+    """The frame format's checksum (csrc/lz4_frame.cpp) against the published test values and the xxhash package."""
+    assert slz4.xxh32(b"") == 0x02CC5D05
+    assert slz4.xxh32(b"", 1) == 0x0B2CB792
+    assert slz4.xxh32(b"a") == 0x550D7456
+    assert slz4.xxh32(b"abc") == 0x32D153FF
+    # the header checksum of the frame the reference's own test writes (test/Main.hs:145-151): FLG 0x40, BD 0x40
+    assert (slz4.xxh32(bytes([0x40, 0x40])) >> 8) & 0xFF == 0xC0
+    xxhash = pytest.importorskip("xxhash")
+    rng = random.Random(5)
+    for n in list(range(0, 40)) + [255, 256, 257, 4095, 65536, 100003]:
+        data = bytes(rng.getrandbits(8) for _ in range(n))
+        seed = rng.getrandbits(32)
+        assert slz4.xxh32(data, seed) == xxhash.xxh32(data, seed=seed).intdigest(), (n, seed)
+
+
 def test_index_host(slz4, oracle):
     data, fr = _stream(oracle, n_blocks=5, bl=1234)
     src = np.frombuffer(fr, dtype=np.uint8)
