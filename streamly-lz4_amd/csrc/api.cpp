@@ -151,6 +151,7 @@ struct mi355lz4_ctx {
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
     DevBuf tolPool, tolMeta;                // deferred-copy decode of a long linked stream (linked_replay.hpp)
+    DevBuf linkBuf, ptrBuf, pinStat;        // ... its failure count, control block and source pointers (linked_ptr.hpp)
     DevBuf pinIn, pinOut;   // pinned host staging
     DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
     hipStream_t sIn = nullptr, sOut = nullptr;   // copy streams of the pipelined host-buffer API (created on first use)
@@ -295,8 +296,9 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
-                      &c->tolPool, &c->tolMeta})
+                      &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf})
         dev_release(*b);
+    pin_release(c->pinStat);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
     pin_release(c->pinMeta);
@@ -455,25 +457,57 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.dict0 = dict0; a.dict0Len = dict0Len;
     a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
-    if (linked && !streamFirst) {
-        // one long linked stream: lists of deferred matches for up to tolMaxRegions dependent blocks per call
-        // (64 KiB each); blocks beyond that, and calls made without the pool, take the serial path
-        static const int tolMaxRegions = [] { const char *e = getenv("MI355LZ4_LINKED_POOL_BLOCKS"); return e ? atoi(e) : 4096; }();
-        const int regions = (nBlocks < tolMaxRegions) ? nBlocks : tolMaxRegions;
-        if (regions > 0 && dev_reserve(c->tolPool, (size_t)regions * tol_region_bytes()) == 0 &&
-            dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
-            a.tolPool = c->tolPool.p; a.tolRegions = regions;
-            a.tolCounter = (uint32_t *)c->tolMeta.p;
-            a.tolRegion = (int32_t *)c->tolMeta.p + 4;
-            a.tolCount = a.tolRegion + nBlocks;
-            a.tolSize = a.tolCount + nBlocks;
-        }
+    a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
+    const bool oneStream = linked && !streamFirst;
+    int r;
+    if (oneStream) {
+        // the standalone pass counts the blocks that need their dictionary: {count, first, last}
+        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes())) || (r = pin_reserve(c->pinStat, 16))) return r;
+        a.linkStat = (uint32_t *)c->linkBuf.p;
+        HIP_TRY(hipMemsetAsync(a.linkStat, 0, 16, c->stream));
+        HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
     }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
-    if (linked) launch_decode_fixup_linked(a, c->stream);
+    if (!linked) return check_launch("decode launch");
+    if (!oneStream) {
+        launch_decode_fixup_linked(a, c->stream);
+        return check_launch("decode launch");
+    }
+    // One long linked stream.  Whether there is a second pass at all, and over which blocks, is decided here: the
+    // call waits for the standalone pass (a stream of independent blocks pays this wait and nothing else).
+    uint32_t *stat = (uint32_t *)c->pinStat.p;
+    HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stat[0] == 0) return check_launch("decode launch");
+    const int first = (int)stat[1], last = (int)stat[2];
+    if (first < 0 || last >= nBlocks || first > last) return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
+    // lists of deferred matches for up to tolMaxRegions dependent blocks at a time (64 KiB each) and four bytes of
+    // source pointer per output byte of such a segment; without them the blocks are walked one after the other
+    static const int tolMaxRegions = [] { const char *e = getenv("MI355LZ4_LINKED_POOL_BLOCKS"); return e ? atoi(e) : 4096; }();
+    static const bool usePtr = [] { const char *e = getenv("MI355LZ4_LINKED_PTR"); return !e || atoi(e) != 0; }();
+    const int span = last - first + 1;
+    const int seg = (tolMaxRegions > 0) ? ((span < tolMaxRegions) ? span : tolMaxRegions) : span;
+    if (tolMaxRegions > 0 && dev_reserve(c->tolPool, (size_t)seg * tol_region_bytes()) == 0 &&
+        dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
+        a.tolPool = c->tolPool.p; a.tolRegions = seg;
+        a.tolCounter = (uint32_t *)c->tolMeta.p;
+        a.tolRegion = (int32_t *)c->tolMeta.p + 4;
+        a.tolCount = a.tolRegion + nBlocks;
+        a.tolSize = a.tolCount + nBlocks;
+        const size_t ptrs = ((size_t)seg + 1) * 65536 + 65536;
+        if (usePtr && dev_reserve(c->ptrBuf, ptrs * sizeof(uint32_t)) == 0) {
+            a.ptr = (uint32_t *)c->ptrBuf.p; a.ptrCap = ptrs;
+            a.ptrCtl = (uint8_t *)c->linkBuf.p + 64;
+        }
+    }
+    for (int b = first; b <= last; b += seg) {
+        a.segFirst = b;
+        a.segEnd = (last + 1 - b < seg) ? last + 1 : b + seg;
+        launch_decode_fixup_linked(a, c->stream);
+    }
     return check_launch("decode launch");
 }
 

@@ -38,6 +38,12 @@ struct DecodeArgs {
     int32_t *tolRegion;           // per block: region index, or -1 (no list: serial path)
     int32_t *tolCount;            // per block: entries appended (may exceed the capacity: overflow)
     int32_t *tolSize;             // per block: result of the tolerant decode
+    // one long linked stream, data-parallel second pass (linked_ptr.hpp)
+    uint32_t *linkStat;           // filled by the standalone pass: {blocks with a codec error, first, last}
+    int segFirst, segEnd;         // blocks the second-pass kernels cover in this launch
+    uint32_t *ptr;                // source pointers of the segment's bytes
+    uint64_t ptrCap;              // ... capacity in pointers
+    void *ptrCtl;                 // PtrCtl
 };
 
 struct EncodeArgs {
@@ -58,7 +64,8 @@ struct EncodeArgs {
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32
-void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);
+void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);   // covers blocks [a.segFirst, a.segEnd)
+size_t ptr_ctl_bytes();
 size_t tol_region_bytes();
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,

@@ -12,6 +12,7 @@
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
 #include "linked_replay.hpp"
+#include "linked_ptr.hpp"
 #include "encode_wave.hpp"
 
 using namespace lz4dev;
@@ -43,6 +44,18 @@ __device__ __forceinline__ int read_block_header(const DecodeArgs &a, int blk, c
     return 0;
 }
 
+// A codec error (not a header rejection) is what a block of a linked stream reports when it is decoded without
+// its dictionary: the second pass is launched only when the standalone pass counted some.
+__device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7F000000; }
+__device__ __forceinline__ void note_link_failure(const DecodeArgs &a, int blk, int r)
+{
+    if (a.linkStat && is_codec_error(r)) {
+        atomicAdd(&a.linkStat[0], 1u);
+        atomicMin(&a.linkStat[1], (uint32_t)blk);
+        atomicMax(&a.linkStat[2], (uint32_t)blk);
+    }
+}
+
 // One wavefront per block, 4 blocks per 256-thread workgroup.
 __global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
 {
@@ -54,7 +67,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
     if (r == 0)
         r = decode_block_seq(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                              a.framed + a.framedLen);
-    if (lane_id() == 0) a.result[blk] = r;
+    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r); }
 }
 
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
@@ -293,7 +306,7 @@ __global__ PAR_OCC void k_decode_par(DecodeArgs a, unsigned long long *stats)
     if (r == 0)
         r = decode_block_par<STATS, false>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                                     a.framed + a.framedLen, lds, stats);
-    if (lane_id() == 0) a.result[blk] = r;
+    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r); }
 }
 
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s)
@@ -356,16 +369,17 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 // already decoded every failed block in parallel and left a list of the matches that (transitively) need the
 // previous block (TolCtx, decode_seq.hpp).  The walk only replays those lists, in LDS (linked_replay.hpp);
 // a block without a usable list is re-decoded by the exact serial decoder with its dictionary.
-__device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7F000000; }
-
 struct TolLds { ParLds p; TolCtx t; };
 
 // (its out-of-line callee is decode_seq_run_tol, which no other kernel calls: the register bound can be its own)
 __global__ __launch_bounds__(64, 3) void k_decode_tolerant(DecodeArgs a)
 {
     __shared__ TolLds lds;
-    const int blk = (int)blockIdx.x;
-    if (!is_codec_error(uni(a.result[blk]))) return;
+    const int blk = a.segFirst + (int)blockIdx.x;
+    if (!is_codec_error(uni(a.result[blk]))) {
+        if (lane_id() == 0) a.tolRegion[blk] = -1;
+        return;
+    }
     const uint8_t *data = nullptr;
     int compLen = 0, cap = 0;
     int region = -1, count = 0, size = -1;
@@ -409,31 +423,31 @@ void k_decode_fixup_regions(DecodeArgs a)
     __shared__ unsigned long long startMask;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
-    const int base = (int)blockIdx.x * LZ4_WAVE;
+    const int base = a.segFirst + (int)blockIdx.x * LZ4_WAVE;
+    if (a.ptrCtl && !((const PtrCtl *)a.ptrCtl)->bad) return;      // the data-parallel pass has done the segment
     if (wave == 0) {
         const int blk = base + tid;
-        const int r0 = (blk < a.nBlocks) ? a.result[blk] : 1;
-        const int rp = (blk > 0 && blk < a.nBlocks) ? a.result[blk - 1] : 1;
-        // block 0 of a range continues whatever region the blocks before the range ended in
-        const bool startsRegion = blk < a.nBlocks && r0 <= 0 && (blk == 0 || rp > 0);
+        const int r0 = (blk < a.segEnd) ? a.result[blk] : 1;
+        const int rp = (blk > 0 && blk < a.segEnd) ? a.result[blk - 1] : 1;
+        // the first block of a range continues whatever region the blocks before the range ended in
+        const bool startsRegion = blk < a.segEnd && r0 <= 0 && (blk == 0 || blk == a.segFirst || rp > 0);
         const uint64_t m0 = __ballot(startsRegion);
         if (tid == 0) startMask = m0;
     }
     __syncthreads();
     for (uint64_t m = startMask; m; m &= m - 1) {
         int f = base + (int)__builtin_ctzll(m);
-        // the dictionary in force: (pointer, length) are recomputed by every thread from data that is final
+        // the dictionary in force: the last block before f that produced output (they are final), else the
+        // caller's; (pointer, length) are recomputed by every thread
         const uint8_t *dict = nullptr;
         uint32_t dictLen = 0;
-        if (f == 0) {
-            if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
-            for (int j = 1; j <= a.lookBack; j++) {               // the last block before the range that produced output
-                const int rj = a.result[-j];
-                if (rj > 0) { dict = a.out + a.outOff[-j]; dictLen = (uint32_t)rj; break; }
-            }
-        } else { dict = a.out + a.outOff[f - 1]; dictLen = (uint32_t)a.result[f - 1]; }
+        if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
+        for (int j = f - 1; j >= -a.lookBack; j--) {
+            const int rj = a.result[j];
+            if (rj > 0) { dict = a.out + a.outOff[j]; dictLen = (uint32_t)rj; break; }
+        }
         bool dictInLds = false;                                   // rl.buf holds `dict` below RPL_HALF
-        for (; f < a.nBlocks; f++) {
+        for (; f < a.segEnd; f++) {
             if (tid == 0) {
                 const int r = a.result[f];
                 int action = RGN_FIX;
@@ -519,17 +533,194 @@ void k_decode_fixup_regions(DecodeArgs a)
     }
 }
 
+// ---- one long linked stream, data-parallel second pass (linked_ptr.hpp) ----
+// Where the segment's pointer space starts in the output buffer: at the block before its first block (that
+// block's output is the first block's dictionary), or at the first block when there is none.
+__device__ __forceinline__ bool ptr_has_prev(const DecodeArgs &a) { return a.segFirst > 0 || a.lookBack > 0; }
+__device__ __forceinline__ uint64_t ptr_lo(const DecodeArgs &a)
+{
+    return ptr_has_prev(a) ? a.outOff[a.segFirst - 1] : a.outOff[a.segFirst];
+}
+// a block the tolerant pass left a usable list for (stable while the second pass runs: result[] is not)
+__device__ __forceinline__ bool ptr_listed(const DecodeArgs &a, int blk)
+{
+    return blk >= a.segFirst && blk < a.segEnd && a.tolRegion[blk] >= 0 && a.tolSize[blk] > 0 &&
+           a.tolCount[blk] <= TOL_LIST_CAP;
+}
+// decoded size of block blk as far as the second pass knows it, 0 = no output
+__device__ __forceinline__ int ptr_size(const DecodeArgs &a, int blk)
+{
+    const int r = a.result[blk];
+    if (r > 0) return r;
+    return (is_codec_error(r) && ptr_listed(a, blk)) ? a.tolSize[blk] : 0;
+}
+
+// Workgroup i >= 1: block segFirst + i - 1 writes the pointers of its own bytes -- self, then its deferred
+// matches.  Workgroup 0: the bytes in front of the segment (caller's dictionary, block before the segment).
+__global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
+{
+    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
+    uint32_t *P = a.ptr;
+    const int tid = (int)threadIdx.x;
+    const uint64_t lo = ptr_lo(a);
+    auto fail = [&]() { if (tid == 0) atomicOr(&ctl->bad, 1u); };
+    if (blockIdx.x == 0) {
+        uint32_t n = PTR_PRE;
+        if (ptr_has_prev(a)) {
+            const int rp = a.result[a.segFirst - 1];
+            if (rp > 0) n += (uint32_t)rp;
+        }
+        if ((uint64_t)n > a.ptrCap) { fail(); return; }
+        for (uint32_t i = (uint32_t)tid; i < n; i += 256u) P[i] = i | PTR_FINAL;
+        return;
+    }
+    const int blk = a.segFirst + (int)blockIdx.x - 1;
+    const int r = a.result[blk];
+    const bool listed = is_codec_error(r) && ptr_listed(a, blk);
+    if (is_codec_error(r) && !listed) { fail(); return; }          // a dependent block without a list
+    const int size = listed ? a.tolSize[blk] : r;
+    if (size <= 0) return;                                          // no output: nobody points here
+    if (a.outOff[blk] < lo) { fail(); return; }
+    const uint64_t b64 = a.outOff[blk] - lo + PTR_PRE;
+    if (b64 + (uint64_t)size > a.ptrCap || b64 + (uint64_t)size >= (uint64_t)PTR_FINAL) { fail(); return; }
+    const uint32_t bLo = (uint32_t)b64;
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)size; i += 256u) P[bLo + i] = (bLo + i) | PTR_FINAL;
+    if (!listed) return;
+    __syncthreads();
+
+    // the dictionary in force (cbits/lz4.c:2347-2355 with every block in its own allocation): the block before
+    uint32_t dictEnd = PTR_PRE;                                     // pointer index one past the dictionary
+    int dictLen = 0;
+    if (blk > 0 || a.lookBack > 0) {
+        const int ps = ptr_size(a, blk - 1);
+        if (ps <= 0 || a.outOff[blk - 1] < lo) { fail(); return; } // dictionary further back, or none: serial walk
+        dictEnd = (uint32_t)(a.outOff[blk - 1] - lo + PTR_PRE) + (uint32_t)ps;
+        dictLen = ps;
+    } else if (a.dict0) {
+        dictLen = (int)a.dict0Len;
+    }
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    if (read_block_header(a, blk, data, compLen, cap) != 0) { fail(); return; }
+    const TolEntry *list = (const TolEntry *)a.tolPool + (size_t)a.tolRegion[blk] * TOL_LIST_CAP;
+    const int n = a.tolCount[blk];
+    const int lane = tid & 63;
+    bool bad = false;
+    for (int e0 = 0; e0 < n; e0 += 256) {
+        const int e = e0 + tid;
+        int dpos = 0, ml = 0, spos = 0;
+        if (e < n) {
+            const uint64_t w = *(const uint64_t *)(list + e);
+            dpos = (int)(uint32_t)(w & 0xffffu); ml = (int)(uint32_t)((w >> 16) & 0xffffu); spos = (int)(uint32_t)(w >> 32);
+            if (!(ml > 0 && spos < dpos && dpos + ml <= size && spos >= -dictLen)) bad = true;
+            // a match that starts in the dictionary must end LASTLITERALS before the end of the output (:1884-1889)
+            if (spos < 0 && dpos + ml > cap - LZ4_LASTLITERALS) bad = true;
+            if (bad) ml = 0;
+        }
+        // byte j of the match comes from position spos + j: in this block, or (negative) in the dictionary
+        auto srcIdx = [&](int sp) -> uint32_t { return (sp >= 0) ? bLo + (uint32_t)sp : dictEnd - (uint32_t)(-sp); };
+        const int head = min(ml, 8);
+        for (int j = 0; j < head; j++) P[bLo + (uint32_t)(dpos + j)] = srcIdx(spos + j);
+        for (uint64_t lm = __ballot(ml > 8); lm; lm &= lm - 1) {   // the rest of a long match: by the whole wave
+            const int k = (int)__builtin_ctzll(lm);
+            const int kd = __builtin_amdgcn_readlane(dpos, k), ks = __builtin_amdgcn_readlane(spos, k);
+            const int kml = __builtin_amdgcn_readlane(ml, k);
+            for (int j = 8 + lane; j < kml; j += LZ4_WAVE) P[bLo + (uint32_t)(kd + j)] = srcIdx(ks + j);
+        }
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) fail();
+}
+
+// One pass of pointer jumping over the bytes of the listed blocks (PTR_PARTS workgroups per block).  Reads of
+// pointers another thread is updating are harmless: every value a pointer ever holds is an ancestor.
+__global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
+{
+    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
+    if (ctl->bad || (pass > 0 && !ctl->changed[pass - 1])) return;
+    const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
+    if (!ptr_listed(a, blk) || !is_codec_error(a.result[blk])) return;
+    uint32_t *P = a.ptr;
+    const uint32_t bLo = (uint32_t)(a.outOff[blk] - ptr_lo(a) + PTR_PRE);
+    const int size = a.tolSize[blk];
+    const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
+    const int x0 = (int)(blockIdx.x % PTR_PARTS) * per, x1 = min(size, x0 + per);
+    bool open = false;
+    for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
+        uint32_t e = P[bLo + (uint32_t)x];
+        if (e & PTR_FINAL) continue;
+#pragma unroll
+        for (int k = 0; k < PTR_JUMPS; k++) {
+            e = P[e];
+            if (e & PTR_FINAL) break;
+        }
+        P[bLo + (uint32_t)x] = e;
+        if (!(e & PTR_FINAL)) open = true;
+    }
+    if (__syncthreads_or(open ? 1 : 0) && threadIdx.x == 0) {
+        ctl->changed[pass] = 1u;
+        if (pass == PTR_MAX_PASSES - 1) ctl->bad = 1u;     // cannot happen (8^passes > pointers); never guess
+    }
+}
+
+// Every deferred byte is fetched from its root; the block's result becomes its size.
+__global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
+{
+    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
+    if (ctl->bad) return;
+    const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
+    if (!ptr_listed(a, blk) || !is_codec_error(a.result[blk])) return;
+    const uint32_t *P = a.ptr;
+    const uint64_t lo = ptr_lo(a);
+    const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
+    const int size = a.tolSize[blk];
+    const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
+    const int part = (int)(blockIdx.x % PTR_PARTS);
+    const int x0 = part * per, x1 = min(size, x0 + per);
+    uint8_t *dst = a.out + a.outOff[blk];
+    const uint8_t *outLo = a.out + lo;
+    const uint8_t *dictTail = a.dict0 ? a.dict0 + a.dict0Len : nullptr;      // index PTR_PRE - d is dictTail[-d]
+    for (int x = x0 + 4 * (int)threadIdx.x; x < x1; x += 4 * 256) {
+        const int n = min(4, x1 - x);
+        for (int j = 0; j < n; j++) {
+            const uint32_t self = bLo + (uint32_t)(x + j);
+            const uint32_t e = P[self] & ~PTR_FINAL;
+            if (e == self) continue;
+            dst[x + j] = (e >= PTR_PRE) ? outLo[e - PTR_PRE] : dictTail[(int)e - (int)PTR_PRE];
+        }
+    }
+}
+
+// ... and only then do the results change: the passes above tell a dependent block by its standalone result.
+__global__ __launch_bounds__(256) void k_ptr_finish(DecodeArgs a)
+{
+    const PtrCtl *ctl = (const PtrCtl *)a.ptrCtl;
+    if (ctl->bad) return;
+    const int blk = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
+    if (blk < a.segEnd && ptr_listed(a, blk) && is_codec_error(a.result[blk])) a.result[blk] = a.tolSize[blk];
+}
+
 size_t tol_region_bytes() { return (size_t)TOL_LIST_CAP * sizeof(TolEntry); }
+size_t ptr_ctl_bytes() { return sizeof(PtrCtl); }
 
 void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
 {
-    if (a.nBlocks <= 0) return;
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
     if (!a.streamFirst) {
         if (a.tolPool) {
             hipMemsetAsync(a.tolCounter, 0, 4 * sizeof(uint32_t), s);
-            hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)n), dim3(64), 0, s, a);
+            if (a.ptr && a.ptrCtl) {
+                hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl), s);
+                hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
+                for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
+                    hipLaunchKernelGGL(k_ptr_jump, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a, pass);
+                hipLaunchKernelGGL(k_ptr_fetch, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+            }
         }
-        hipLaunchKernelGGL(k_decode_fixup_regions, dim3((unsigned)((a.nBlocks + LZ4_WAVE - 1) / LZ4_WAVE)),
+        // whatever the pass above did not take (PtrCtl::bad, or no pool): the walk, block after block
+        hipLaunchKernelGGL(k_decode_fixup_regions, dim3((unsigned)((n + LZ4_WAVE - 1) / LZ4_WAVE)),
                            dim3(RPL_THREADS), 0, s, a);
         return;
     }

@@ -1,0 +1,41 @@
+// linked_ptr.hpp -- second pass of the deferred-copy decode of ONE long linked stream, without the serial walk.
+//
+// The tolerant pass (decode_par.hpp / decode_seq.hpp, TolCtx) has decoded every dependent block in parallel and
+// left, per block, the list of matches it could not copy: those that start in the previous block's output
+// (cbits/lz4.c:1883-1911, the ext-dict case of LZ4_decompress_safe_continue, :2347-2355) and those that read
+// bytes such a match produces.  What is still missing is data, not structure: WHERE every byte of the stream
+// comes from is known, all the way back, because a block's size and its match offsets depend on its tokens
+// only.  So the chain of blocks is not walked.  Every byte of the segment gets a source pointer -- itself
+// (literal, or already copied) or the byte its deferred match names, in the block or in the block before --
+// and pointer jumping (P[x] = P[P[x]]) resolves all chains at once, in log(depth) passes over the pointers;
+// a last pass fetches each deferred byte from its root.  All of it is data-parallel over the whole segment:
+// the rate no longer depends on how many streams there are.
+//
+// Pointer coordinates: index PTR_PRE + d is the byte d bytes behind `lo` in the output buffer (lo = start of
+// the block before the segment's first block: its dictionary); indices below PTR_PRE are the last bytes of the
+// caller's dictionary (dict0), which only block 0 of a call can reach.  The top bit marks a pointer that
+// already names a root.
+//
+// Anything the reference would not have accepted (an offset beyond the dictionary, :1764; a dictionary match
+// that ends inside the last literals, :1884-1889), and any block without a usable list, sets PtrCtl::bad: the
+// segment is then left untouched and walked by linked_replay.hpp / the exact decoder, which also yields the
+// reference's error codes.
+#pragma once
+
+#include "decode_par.hpp"
+#include "linked_replay.hpp"
+
+namespace lz4dev {
+
+#define PTR_FINAL 0x80000000u
+#define PTR_PRE 65536u
+#define PTR_JUMPS 3                // dependent jumps per pass: the depth shrinks 8-fold per launch
+#define PTR_MAX_PASSES 12          // 8^11 > 2^31 pointers
+#define PTR_PARTS 4                // workgroups per block in the jump / fetch passes
+
+struct PtrCtl {
+    uint32_t bad;                           // the segment goes to the serial walk
+    uint32_t changed[PTR_MAX_PASSES + 1];   // pass r left unresolved pointers behind
+};
+
+} // namespace lz4dev

@@ -14,3 +14,4 @@ void launch_compact(const uint8_t *, size_t, const int32_t *, int, uint8_t *, si
 void launch_interleave(const uint8_t *, const uint64_t *, int, int, int, uint8_t *, const uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_index(const uint8_t *, uint64_t, const uint64_t *, int, int, int, int32_t *, uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_generate(int, uint8_t *, int, int, uint64_t, uint64_t, uint32_t, uint32_t, hipStream_t) { UNREACHABLE_LAUNCH; }
+size_t ptr_ctl_bytes() { return 64; }
