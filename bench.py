@@ -62,6 +62,36 @@ def canterbury_large(n_bytes):
     return b"".join(parts), "Canterbury large (bible.txt, E.coli, world192.txt cycled)"
 
 
+def reference_stream_decode(S, eng, torch, dev, comps, src, ns, BL):
+    """GPU decode (linked = 1) of a stream of `ns` blocks written by the reference's linked compressor."""
+    import struct
+    import numpy as np
+    framed = b"".join(struct.pack("<ii", len(c), BL) + c for c in comps)
+    offs = np.zeros(ns + 1, dtype=np.int64)
+    np.cumsum([8 + len(c) for c in comps], out=offs[1:])
+    buf = torch.from_numpy(np.frombuffer(framed, dtype=np.uint8).copy()).to(dev)
+    off = torch.from_numpy(offs).to(dev)
+    ooff = torch.arange(ns + 1, dtype=torch.int64, device=dev) * BL
+    out = torch.zeros(ns * BL, dtype=torch.uint8, device=dev)
+    res = torch.zeros(ns, dtype=torch.int32, device=dev)
+    eng.decompress_batch_device(buf, len(framed), off, ns, out, ooff, res, linked=False)
+    eng.synchronize()
+    dependent = int((res < 0).sum().item())
+    e0, e1 = S.Event(), S.Event()
+    best = 1e9
+    for _ in range(3):
+        eng.record(e0)
+        eng.decompress_batch_device(buf, len(framed), off, ns, out, ooff, res, linked=True)
+        eng.record(e1)
+        eng.synchronize()
+        best = min(best, eng.elapsed_ms(e0, e1))
+    ok = bool((res == BL).all().item()) and torch.equal(out, src[: ns * BL])
+    if not ok:
+        sys.exit("bench.py: the reference-written linked stream does not decode to the input")
+    return {"blocks": ns, "dependent_blocks": dependent, "ms": round(best, 3), "GBps": round(ns * BL / best / 1e6, 2),
+            "verified": True, "note": "one linked stream, one call; device-resident, HIP events"}
+
+
 def host_api_rates(S, eng, src, BL, kind):
     """PCIe-inclusive rate of the host-buffer C API (what the Haskell shim binds) on the first 512 MiB of the
     same stream: pageable caller memory (staged through pinned slots) and page-locked caller memory (DMA
@@ -343,7 +373,7 @@ def main():
         ns = args.cpu_sample_blocks or min(NB, (1 << 30) // BL)                # <= 1 GiB of the same stream
         host = src[: ns * BL].cpu().numpy()
         blocks = [host[i * BL:(i + 1) * BL].tobytes() for i in range(ns)]
-        r = orc.cpu_baseline(blocks, accel=accel)
+        r = orc.cpu_baseline(blocks, accel=accel, keep_stream=True)
         cpu_dec = r["raw_bytes"] / r["decomp_s"] / 1e9
         cpu_cmp = r["raw_bytes"] / r["comp_s"] / 1e9
         gpu_sample_bytes = int(doff[ns].item())
@@ -355,6 +385,10 @@ def main():
                "ratio": round(r["raw_bytes"] / (r["comp_bytes"] + 8 * ns), 4),
                "gpu_ratio_same_sample": round(ns * BL / gpu_sample_bytes, 4),
                "gpu_size_vs_reference": round(gpu_sample_bytes / (r["comp_bytes"] + 8 * ns), 4)}
+        # The stream the reference wrote for this sample (one linked context: nearly every block needs the output of
+        # the block before it) decoded by the GPU in one call, linked = 1, and compared with the input.
+        cpu["reference_stream_gpu_decode"] = reference_stream_decode(S, eng, torch, dev, r["stream"], src, ns, BL)
+        del r["stream"]
         if not args.no_cpu_all_cores:
             # best-case CPU, NOT reference behaviour (its API is one serial stream): one independent
             # linked context per host thread over contiguous block ranges of the same sample

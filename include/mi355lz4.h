@@ -120,9 +120,13 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * of the last block before it that decoded to > 0 bytes, exactly as under
  * LZ4_decompress_safe_continue with separately allocated blocks
  * (cbits/lz4.c:2322-2359); blocks must be given in stream order.  Blocks that
- * decode on their own (everything this engine's compressor emits) still go
- * through the parallel kernel; only blocks that reach into their predecessor
- * are re-decoded in stream order.
+ * decode on their own (everything this engine's compressor emits) are final
+ * after the parallel kernel; blocks that reach into their predecessor are
+ * resolved by a second, data-parallel pass (source pointers + pointer jumping,
+ * DESIGN.md 1).  With linked != 0 the call WAITS for the first pass on the
+ * engine's stream (it reads back how many blocks need the second pass and
+ * sizes it; scratch: 1 + 4 bytes per output byte of up to 4096 such blocks at a
+ * time); with linked == 0 it only enqueues work.
  * replaces: decompressChunk, Internal/LZ4.hs:291-336. */
 int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
                                      const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,

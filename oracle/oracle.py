@@ -260,13 +260,18 @@ def cpu_baseline_all_cores(blocks, accel=1, threads=None, reps=2):
             "raw_bytes": int(sum(int(j.lens.sum()) for j in jobs)), "comp_bytes": int(sum(int(j.clens.sum()) for j in jobs))}
 
 
-def cpu_baseline(blocks, accel=1, reps=3):
+def cpu_baseline(blocks, accel=1, reps=3, keep_stream=False):
     """Time compress+decompress of `blocks` (list of bytes) with the reference call
     sequence on ONE host thread.  Returns dict(kind, comp_s, decomp_s, comp_bytes).
+    keep_stream: also return the compressed blocks ("stream": list of bytes) -- the linked stream the
+    reference writes for this input, which bench.py hands to the GPU decoder.
     Used only by bench.py's cpu_baseline leg."""
     job = _CpuJob(blocks, accel)
     best_c = min(job.compress() for _ in range(reps))
     best_d = min(job.decompress() for _ in range(reps))
     job.verify()
-    return {"kind": job.kind, "comp_s": best_c, "decomp_s": best_d, "comp_bytes": int(job.clens.sum()),
-            "raw_bytes": int(job.lens.sum())}
+    r = {"kind": job.kind, "comp_s": best_c, "decomp_s": best_d, "comp_bytes": int(job.clens.sum()),
+         "raw_bytes": int(job.lens.sum())}
+    if keep_stream:
+        r["stream"] = [c[:int(n)].tobytes() for c, n in zip(job.comps, job.clens)]
+    return r

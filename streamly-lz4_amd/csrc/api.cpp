@@ -458,11 +458,12 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
-    const bool oneStream = linked && !streamFirst;
+    a.ptrBad = nullptr;
+    const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
-    if (oneStream) {
+    if (linked) {
         // the standalone pass counts the blocks that need their dictionary: {count, first, last}
-        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes())) || (r = pin_reserve(c->pinStat, 16))) return r;
+        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 16))) return r;
         a.linkStat = (uint32_t *)c->linkBuf.p;
         HIP_TRY(hipMemsetAsync(a.linkStat, 0, 16, c->stream));
         HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
@@ -472,41 +473,57 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     else
         launch_decode_par(a, c->stats, c->stream);
     if (!linked) return check_launch("decode launch");
-    if (!oneStream) {
-        launch_decode_fixup_linked(a, c->stream);
-        return check_launch("decode launch");
-    }
-    // One long linked stream.  Whether there is a second pass at all, and over which blocks, is decided here: the
+    // Linked streams.  Whether there is a second pass at all, and over which blocks, is decided here: the
     // call waits for the standalone pass (a stream of independent blocks pays this wait and nothing else).
     uint32_t *stat = (uint32_t *)c->pinStat.p;
+    launch_longest_stream(a, c->stream);
     HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (stat[0] == 0) return check_launch("decode launch");
     const int first = (int)stat[1], last = (int)stat[2];
     if (first < 0 || last >= nBlocks || first > last) return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
-    // lists of deferred matches for up to tolMaxRegions dependent blocks at a time (64 KiB each) and four bytes of
-    // source pointer per output byte of such a segment; without them the blocks are walked one after the other
-    static const int tolMaxRegions = [] { const char *e = getenv("MI355LZ4_LINKED_POOL_BLOCKS"); return e ? atoi(e) : 4096; }();
-    static const bool usePtr = [] { const char *e = getenv("MI355LZ4_LINKED_PTR"); return !e || atoi(e) != 0; }();
+    // Lists of deferred matches for up to POOL_BLOCKS dependent blocks at a time (64 KiB each: one byte per output
+    // byte) and source pointers for up to PTR_BLOCKS of them (four bytes per output byte); without the lists the
+    // blocks are walked one after the other.  (Read per call: the tests shrink both to reach every seam.)
+    const char *envPool = getenv("MI355LZ4_LINKED_POOL_BLOCKS"), *envPtr = getenv("MI355LZ4_LINKED_PTR"),
+               *envSeg = getenv("MI355LZ4_LINKED_PTR_BLOCKS");
+    const int poolMax = envPool ? atoi(envPool) : 16384;
+    const int ptrMax = (envSeg && atoi(envSeg) > 0) ? atoi(envSeg) : 4096;
+    const bool usePtr = !envPtr || atoi(envPtr) != 0;
+    // Many short streams are walked side by side, one wavefront per stream, faster than their bytes are resolved
+    // through pointers: a walk costs ~0.42 ms per dependent block of the longest stream (up to ~5000 streams at a
+    // time), the pointer passes ~0.6 ms + 1.4 us per dependent block of the call (MI355X, text-like data).
+    const bool walkStreams = streamFirst && !getenv("MI355LZ4_LINKED_PTR") &&
+                             0.42 * (double)(stat[3] > 0 ? stat[3] - 1 : 0) * (double)(1 + nStreams / 5000) <
+                                 0.6 + 1.4e-3 * (double)stat[0];
     const int span = last - first + 1;
-    const int seg = (tolMaxRegions > 0) ? ((span < tolMaxRegions) ? span : tolMaxRegions) : span;
-    if (tolMaxRegions > 0 && dev_reserve(c->tolPool, (size_t)seg * tol_region_bytes()) == 0 &&
+    const int pool = (poolMax > 0 && !walkStreams) ? ((span < poolMax) ? span : poolMax) : span;
+    int seg = pool;
+    if (poolMax > 0 && !walkStreams && dev_reserve(c->tolPool, (size_t)pool * tol_region_bytes()) == 0 &&
         dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
-        a.tolPool = c->tolPool.p; a.tolRegions = seg;
+        a.tolPool = c->tolPool.p; a.tolRegions = pool;
         a.tolCounter = (uint32_t *)c->tolMeta.p;
         a.tolRegion = (int32_t *)c->tolMeta.p + 4;
         a.tolCount = a.tolRegion + nBlocks;
         a.tolSize = a.tolCount + nBlocks;
-        const size_t ptrs = ((size_t)seg + 1) * 65536 + 65536;
+        const int pseg = (pool < ptrMax) ? pool : ptrMax;
+        const size_t ptrs = ((size_t)pseg + 1) * 65536 + 65536;
         if (usePtr && dev_reserve(c->ptrBuf, ptrs * sizeof(uint32_t)) == 0) {
             a.ptr = (uint32_t *)c->ptrBuf.p; a.ptrCap = ptrs;
             a.ptrCtl = (uint8_t *)c->linkBuf.p + 64;
+            a.ptrBad = (uint32_t *)((uint8_t *)c->linkBuf.p + 64 + ptr_ctl_bytes());
+            seg = pseg;
         }
     }
-    for (int b = first; b <= last; b += seg) {
-        a.segFirst = b;
-        a.segEnd = (last + 1 - b < seg) ? last + 1 : b + seg;
-        launch_decode_fixup_linked(a, c->stream);
+    for (int p0 = first; p0 <= last; p0 += pool) {
+        const int p1 = (last + 1 - p0 < pool) ? last + 1 : p0 + pool;
+        a.segFirst = p0; a.segEnd = p1;
+        launch_linked_tolerant(a, c->stream);
+        for (int b = p0; b < p1; b += seg) {
+            a.segFirst = b;
+            a.segEnd = (p1 - b < seg) ? p1 : b + seg;
+            launch_linked_resolve(a, c->stream);
+        }
     }
     return check_launch("decode launch");
 }

@@ -44,6 +44,7 @@ struct DecodeArgs {
     uint32_t *ptr;                // source pointers of the segment's bytes
     uint64_t ptrCap;              // ... capacity in pointers
     void *ptrCtl;                 // PtrCtl
+    uint32_t *ptrBad;             // per stream (one entry without streamFirst): left to the serial walk
 };
 
 struct EncodeArgs {
@@ -64,7 +65,9 @@ struct EncodeArgs {
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32
-void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s);   // covers blocks [a.segFirst, a.segEnd)
+void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s);   // both cover blocks [a.segFirst, a.segEnd)
+void launch_linked_resolve(const DecodeArgs &a, hipStream_t s);
+void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);

@@ -331,6 +331,7 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 {
     __shared__ ParLds lds;
     const int sIdx = (int)blockIdx.x;
+    if (a.ptrBad && !a.ptrBad[sIdx]) return;                        // the data-parallel pass has done this stream
     int b0 = 0, b1 = a.nBlocks;
     const uint8_t *dict = nullptr;
     uint32_t dictLen = 0;
@@ -424,7 +425,7 @@ void k_decode_fixup_regions(DecodeArgs a)
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
     const int base = a.segFirst + (int)blockIdx.x * LZ4_WAVE;
-    if (a.ptrCtl && !((const PtrCtl *)a.ptrCtl)->bad) return;      // the data-parallel pass has done the segment
+    if (a.ptrBad && !a.ptrBad[0]) return;                           // the data-parallel pass has done the segment
     if (wave == 0) {
         const int blk = base + tid;
         const int r0 = (blk < a.segEnd) ? a.result[blk] : 1;
@@ -541,6 +542,22 @@ __device__ __forceinline__ uint64_t ptr_lo(const DecodeArgs &a)
 {
     return ptr_has_prev(a) ? a.outOff[a.segFirst - 1] : a.outOff[a.segFirst];
 }
+// The stream a block belongs to (index into ptrBad[]; -1 = none: decoded on its own) and whether the block
+// before it is its dictionary.  One stream: every block but the very first has one.
+__device__ __forceinline__ int ptr_stream(const DecodeArgs &a, int blk, bool &hasDict)
+{
+    if (!a.streamFirst) { hasDict = blk > 0 || a.lookBack > 0; return 0; }
+    auto first = [&](int s) { return min(max(a.streamFirst[s], 0), a.nBlocks); };
+    hasDict = false;
+    if (a.nStreams <= 0 || blk < first(0) || blk >= first(a.nStreams)) return -1;
+    int lo = 0, hi = a.nStreams;                       // first(lo) <= blk < first(hi)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (first(mid) <= blk) lo = mid; else hi = mid;
+    }
+    hasDict = blk > first(lo);
+    return lo;
+}
 // a block the tolerant pass left a usable list for (stable while the second pass runs: result[] is not)
 __device__ __forceinline__ bool ptr_listed(const DecodeArgs &a, int blk)
 {
@@ -555,26 +572,36 @@ __device__ __forceinline__ int ptr_size(const DecodeArgs &a, int blk)
     return (is_codec_error(r) && ptr_listed(a, blk)) ? a.tolSize[blk] : 0;
 }
 
+// a dependent block the second pass is resolving: listed, and nothing in its stream was turned down
+__device__ __forceinline__ bool ptr_taken(const DecodeArgs &a, int blk)
+{
+    if (!ptr_listed(a, blk) || !is_codec_error(a.result[blk])) return false;
+    bool hd;
+    const int sid = ptr_stream(a, blk, hd);
+    return sid >= 0 && !a.ptrBad[sid];
+}
+
 // Workgroup i >= 1: block segFirst + i - 1 writes the pointers of its own bytes -- self, then its deferred
 // matches.  Workgroup 0: the bytes in front of the segment (caller's dictionary, block before the segment).
 __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 {
-    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     uint32_t *P = a.ptr;
     const int tid = (int)threadIdx.x;
     const uint64_t lo = ptr_lo(a);
-    auto fail = [&]() { if (tid == 0) atomicOr(&ctl->bad, 1u); };
     if (blockIdx.x == 0) {
         uint32_t n = PTR_PRE;
         if (ptr_has_prev(a)) {
             const int rp = a.result[a.segFirst - 1];
             if (rp > 0) n += (uint32_t)rp;
         }
-        if ((uint64_t)n > a.ptrCap) { fail(); return; }
+        n = (uint32_t)min((uint64_t)n, a.ptrCap);      // (the first block checks its own range against the capacity)
         for (uint32_t i = (uint32_t)tid; i < n; i += 256u) P[i] = i | PTR_FINAL;
         return;
     }
     const int blk = a.segFirst + (int)blockIdx.x - 1;
+    bool hasDict = false;
+    const int sid = ptr_stream(a, blk, hasDict);
+    auto fail = [&]() { if (tid == 0 && sid >= 0) atomicOr(&a.ptrBad[sid], 1u); };
     const int r = a.result[blk];
     const bool listed = is_codec_error(r) && ptr_listed(a, blk);
     if (is_codec_error(r) && !listed) { fail(); return; }          // a dependent block without a list
@@ -591,12 +618,12 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
     // the dictionary in force (cbits/lz4.c:2347-2355 with every block in its own allocation): the block before
     uint32_t dictEnd = PTR_PRE;                                     // pointer index one past the dictionary
     int dictLen = 0;
-    if (blk > 0 || a.lookBack > 0) {
+    if (hasDict) {
         const int ps = ptr_size(a, blk - 1);
         if (ps <= 0 || a.outOff[blk - 1] < lo) { fail(); return; } // dictionary further back, or none: serial walk
         dictEnd = (uint32_t)(a.outOff[blk - 1] - lo + PTR_PRE) + (uint32_t)ps;
         dictLen = ps;
-    } else if (a.dict0) {
+    } else if (a.dict0 && !a.streamFirst) {
         dictLen = (int)a.dict0Len;
     }
     const uint8_t *data = nullptr;
@@ -636,39 +663,61 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
 {
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
-    if (ctl->bad || (pass > 0 && !ctl->changed[pass - 1])) return;
+    if (pass > 0 && !ctl->changed[pass - 1]) return;
     const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
-    if (!ptr_listed(a, blk) || !is_codec_error(a.result[blk])) return;
+    if (!ptr_taken(a, blk)) return;
     uint32_t *P = a.ptr;
     const uint32_t bLo = (uint32_t)(a.outOff[blk] - ptr_lo(a) + PTR_PRE);
     const int size = a.tolSize[blk];
     const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
     const int x0 = (int)(blockIdx.x % PTR_PARTS) * per, x1 = min(size, x0 + per);
     bool open = false;
-    for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
-        uint32_t e = P[bLo + (uint32_t)x];
-        if (e & PTR_FINAL) continue;
+    auto chase = [&](uint32_t e) -> uint32_t {
 #pragma unroll
         for (int k = 0; k < PTR_JUMPS; k++) {
             e = P[e];
             if (e & PTR_FINAL) break;
         }
-        P[bLo + (uint32_t)x] = e;
         if (!(e & PTR_FINAL)) open = true;
+        return e;
+    };
+    if (((bLo | (uint32_t)x0) & 3u) == 0) {
+        // four pointers per thread (16-byte accesses); the four chains are independent loads in flight
+        uint4 *P4 = (uint4 *)(P + bLo);
+        const int q1 = x1 >> 2;
+        for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
+            uint4 v = P4[q];
+            if ((v.x & v.y & v.z & v.w) & PTR_FINAL) continue;
+            if (!(v.x & PTR_FINAL)) v.x = chase(v.x);
+            if (!(v.y & PTR_FINAL)) v.y = chase(v.y);
+            if (!(v.z & PTR_FINAL)) v.z = chase(v.z);
+            if (!(v.w & PTR_FINAL)) v.w = chase(v.w);
+            P4[q] = v;
+        }
+        for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
+            const uint32_t e = P[bLo + (uint32_t)x];
+            if (!(e & PTR_FINAL)) P[bLo + (uint32_t)x] = chase(e);
+        }
+    } else {
+        for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
+            const uint32_t e = P[bLo + (uint32_t)x];
+            if (!(e & PTR_FINAL)) P[bLo + (uint32_t)x] = chase(e);
+        }
     }
     if (__syncthreads_or(open ? 1 : 0) && threadIdx.x == 0) {
         ctl->changed[pass] = 1u;
-        if (pass == PTR_MAX_PASSES - 1) ctl->bad = 1u;     // cannot happen (8^passes > pointers); never guess
+        if (pass == PTR_MAX_PASSES - 1) {                  // cannot happen (8^passes > pointers); never guess
+            bool hd;
+            atomicOr(&a.ptrBad[ptr_stream(a, blk, hd)], 1u);
+        }
     }
 }
 
 // Every deferred byte is fetched from its root; the block's result becomes its size.
 __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
 {
-    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
-    if (ctl->bad) return;
     const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
-    if (!ptr_listed(a, blk) || !is_codec_error(a.result[blk])) return;
+    if (!ptr_taken(a, blk)) return;
     const uint32_t *P = a.ptr;
     const uint64_t lo = ptr_lo(a);
     const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
@@ -679,13 +728,35 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
     uint8_t *dst = a.out + a.outOff[blk];
     const uint8_t *outLo = a.out + lo;
     const uint8_t *dictTail = a.dict0 ? a.dict0 + a.dict0Len : nullptr;      // index PTR_PRE - d is dictTail[-d]
-    for (int x = x0 + 4 * (int)threadIdx.x; x < x1; x += 4 * 256) {
-        const int n = min(4, x1 - x);
-        for (int j = 0; j < n; j++) {
-            const uint32_t self = bLo + (uint32_t)(x + j);
-            const uint32_t e = P[self] & ~PTR_FINAL;
-            if (e == self) continue;
-            dst[x + j] = (e >= PTR_PRE) ? outLo[e - PTR_PRE] : dictTail[(int)e - (int)PTR_PRE];
+    auto root = [&](uint32_t e) -> uint8_t {
+        return (e >= PTR_PRE) ? outLo[e - PTR_PRE] : dictTail[(int)e - (int)PTR_PRE];
+    };
+    if (((bLo | (uint32_t)x0) & 3u) == 0) {
+        // four bytes per thread: one 16-byte load of pointers, up to four byte fetches, one 4-byte store
+        const uint4 *P4 = (const uint4 *)(P + bLo);
+        const int q1 = x1 >> 2;
+        for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
+            uint4 v = P4[q];
+            v.x &= ~PTR_FINAL; v.y &= ~PTR_FINAL; v.z &= ~PTR_FINAL; v.w &= ~PTR_FINAL;
+            const uint32_t self = bLo + 4u * (uint32_t)q;
+            const bool m0 = v.x != self, m1 = v.y != self + 1u, m2 = v.z != self + 2u, m3 = v.w != self + 3u;
+            if (!(m0 || m1 || m2 || m3)) continue;
+            uint32_t w;
+            __builtin_memcpy(&w, dst + 4 * q, 4);
+            if (m0) w = (w & 0xffffff00u) | (uint32_t)root(v.x);
+            if (m1) w = (w & 0xffff00ffu) | ((uint32_t)root(v.y) << 8);
+            if (m2) w = (w & 0xff00ffffu) | ((uint32_t)root(v.z) << 16);
+            if (m3) w = (w & 0x00ffffffu) | ((uint32_t)root(v.w) << 24);
+            __builtin_memcpy(dst + 4 * q, &w, 4);
+        }
+        for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
+            const uint32_t self = bLo + (uint32_t)x, e = P[self] & ~PTR_FINAL;
+            if (e != self) dst[x] = root(e);
+        }
+    } else {
+        for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
+            const uint32_t self = bLo + (uint32_t)x, e = P[self] & ~PTR_FINAL;
+            if (e != self) dst[x] = root(e);
         }
     }
 }
@@ -693,36 +764,55 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
 // ... and only then do the results change: the passes above tell a dependent block by its standalone result.
 __global__ __launch_bounds__(256) void k_ptr_finish(DecodeArgs a)
 {
-    const PtrCtl *ctl = (const PtrCtl *)a.ptrCtl;
-    if (ctl->bad) return;
     const int blk = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
-    if (blk < a.segEnd && ptr_listed(a, blk) && is_codec_error(a.result[blk])) a.result[blk] = a.tolSize[blk];
+    if (blk < a.segEnd && ptr_taken(a, blk)) a.result[blk] = a.tolSize[blk];
 }
 
 size_t tol_region_bytes() { return (size_t)TOL_LIST_CAP * sizeof(TolEntry); }
 size_t ptr_ctl_bytes() { return sizeof(PtrCtl); }
 
-void launch_decode_fixup_linked(const DecodeArgs &a, hipStream_t s)
+// linkStat[3] = blocks of the longest stream (the serial walk of a stream costs its length)
+__global__ __launch_bounds__(256) void k_longest_stream(DecodeArgs a)
+{
+    const int s = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (s >= a.nStreams) return;
+    const int b0 = min(max(a.streamFirst[s], 0), a.nBlocks), b1 = min(max(a.streamFirst[s + 1], b0), a.nBlocks);
+    atomicMax(&a.linkStat[3], (uint32_t)(b1 - b0));
+}
+
+void launch_longest_stream(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.streamFirst && a.nStreams > 0 && a.linkStat)
+        hipLaunchKernelGGL(k_longest_stream, dim3((unsigned)((a.nStreams + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// Second pass over the blocks [a.segFirst, a.segEnd) of linked streams, in two steps so that the caller can give
+// the first one a longer range than the second (lists are 1 byte per output byte, pointers are 4).
+void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0 || !a.tolPool) return;
+    hipMemsetAsync(a.tolCounter, 0, 4 * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)n), dim3(64), 0, s, a);
+}
+
+void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
 {
     const int n = a.segEnd - a.segFirst;
     if (n <= 0) return;
-    if (!a.streamFirst) {
-        if (a.tolPool) {
-            hipMemsetAsync(a.tolCounter, 0, 4 * sizeof(uint32_t), s);
-            hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)n), dim3(64), 0, s, a);
-            if (a.ptr && a.ptrCtl) {
-                hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl), s);
-                hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
-                for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
-                    hipLaunchKernelGGL(k_ptr_jump, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a, pass);
-                hipLaunchKernelGGL(k_ptr_fetch, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a);
-                hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-            }
-        }
-        // whatever the pass above did not take (PtrCtl::bad, or no pool): the walk, block after block
+    if (a.tolPool && a.ptr && a.ptrCtl && a.ptrBad) {
+        // (the stream flags follow the control block: a stream turned down in one segment gets its chance in the next)
+        hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
+        hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
+        for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
+            hipLaunchKernelGGL(k_ptr_jump, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a, pass);
+        hipLaunchKernelGGL(k_ptr_fetch, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    }
+    // whatever the pass above did not take (ptrBad, or no pool): the walk, block after block
+    if (!a.streamFirst)
         hipLaunchKernelGGL(k_decode_fixup_regions, dim3((unsigned)((n + LZ4_WAVE - 1) / LZ4_WAVE)),
                            dim3(RPL_THREADS), 0, s, a);
-        return;
-    }
-    if (a.nStreams > 0) hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);
+    else if (a.nStreams > 0)
+        hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);
 }

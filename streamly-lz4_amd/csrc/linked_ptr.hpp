@@ -17,9 +17,9 @@
 // already names a root.
 //
 // Anything the reference would not have accepted (an offset beyond the dictionary, :1764; a dictionary match
-// that ends inside the last literals, :1884-1889), and any block without a usable list, sets PtrCtl::bad: the
-// segment is then left untouched and walked by linked_replay.hpp / the exact decoder, which also yields the
-// reference's error codes.
+// that ends inside the last literals, :1884-1889), and any block without a usable list, turns its STREAM down: its blocks
+// are left untouched and walked by linked_replay.hpp / the exact decoder, which also yields the
+// reference's error codes.  (DecodeArgs::ptrBad: one flag per stream.)
 #pragma once
 
 #include "decode_par.hpp"
@@ -34,7 +34,6 @@ namespace lz4dev {
 #define PTR_PARTS 4                // workgroups per block in the jump / fetch passes
 
 struct PtrCtl {
-    uint32_t bad;                           // the segment goes to the serial walk
     uint32_t changed[PTR_MAX_PASSES + 1];   // pass r left unresolved pointers behind
 };
 

@@ -99,10 +99,12 @@ def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
     assert best[True] <= best[False] * 1.02 + 0.02, rec
 
 
-@pytest.mark.parametrize("kind,n_blocks", [("text", 1024), ("lzsynth_shared", 512)])
-def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks):
+@pytest.mark.parametrize("kind,n_blocks,repeat", [("text", 1024, 1), ("lzsynth_shared", 512, 1), ("text", 1024, 10)])
+def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks, repeat):
     """ONE long stream written by the reference's linked compressor (what a reference-written file is): the
-    tolerant parallel pass + the in-order LDS replay (linked_replay.hpp).  Bit-exact; the rate is recorded."""
+    tolerant parallel pass + the data-parallel pointer pass (linked_ptr.hpp).  Bit-exact; the rate is recorded.
+    repeat > 1: the framed stream is appended to itself (still one valid linked stream: a block written without
+    a dictionary may follow any block), long enough to span several segments of the second pass."""
     import torch
     dev = torch.device("cuda:0")
     bl = 65536
@@ -117,8 +119,9 @@ def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks):
             o = int(rng.integers(0, bl))
             parts.append(base[o:o + bl])
         data = b"".join(parts)
-    fr = oracle.frame_compress(data, bl, 1, 8, True)
-    nb = n_blocks
+    fr = oracle.frame_compress(data, bl, 1, 8, True) * repeat
+    data = data * repeat
+    nb = n_blocks * repeat
     offs, pos = [], 0
     for _ in range(nb):
         offs.append(pos)

@@ -529,8 +529,30 @@ def _decode_streams(engine, frs, linked_mode):
     return out[: int(ooff_h[-1])].cpu().numpy().tobytes(), res.cpu().tolist(), ulen, first
 
 
+# The second pass of a linked decode has three implementations behind one contract: byte source pointers +
+# pointer jumping (csrc/linked_ptr.hpp), the in-order replay of deferred lists (csrc/linked_replay.hpp) and the
+# exact decoder block after block.  The environment picks which ones a call may use and how many dependent
+# blocks a segment holds, so that every path and every segment seam sees the same tests.
+LINKED_VARIANTS = {
+    "default": {},
+    "segments_of_3": {"MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
+    "pointer_pass_forced": {"MI355LZ4_LINKED_PTR": "1"},          # (many short streams would be walked otherwise)
+    "pointer_segments_of_2": {"MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_PTR_BLOCKS": "2"},
+    "replay_only": {"MI355LZ4_LINKED_PTR": "0"},
+    "replay_segments_of_2": {"MI355LZ4_LINKED_PTR": "0", "MI355LZ4_LINKED_POOL_BLOCKS": "2"},
+    "serial_only": {"MI355LZ4_LINKED_POOL_BLOCKS": "0"},
+}
+
+
+@pytest.fixture(params=list(LINKED_VARIANTS))
+def linked_variant(request, monkeypatch):
+    for k, v in LINKED_VARIANTS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 @pytest.mark.parametrize("decoder", [1, 2])
-def test_linked_streams_many(engine, oracle, decoder):
+def test_linked_streams_many(engine, oracle, decoder, linked_variant):
     engine.set_decoder(decoder)
     try:
         rng = random.Random(7)
@@ -595,7 +617,7 @@ def test_linked_streams_error_is_local(engine, oracle):
             dict_bytes = dec
 
 
-def test_linked_streams_fuzz_codes(engine, oracle):
+def test_linked_streams_fuzz_codes(engine, oracle, linked_variant):
     """Random single-byte corruptions anywhere in reference-linked streams: every block's result (size or
     negative code) and every decoded byte equals the oracle's linked decode of the same bytes."""
     rng = random.Random(2024)
@@ -638,7 +660,7 @@ def test_linked_streams_fuzz_codes(engine, oracle):
                 assert out[o:o + len(eouts[j])] == eouts[j], (t, j)
 
 
-def test_single_linked_stream_fuzz_codes(engine, oracle):
+def test_single_linked_stream_fuzz_codes(engine, oracle, linked_variant):
     """ONE reference-linked stream per call (linked = 1: tolerant parallel pass + in-order replay,
     csrc/linked_replay.hpp) with corruptions of payload bytes: every block's result (size or the reference's
     negative code, cbits/lz4.c:2163) and every decoded byte equals the oracle's linked decode, block by block
