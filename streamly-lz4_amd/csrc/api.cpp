@@ -1082,20 +1082,29 @@ static int decompress_host_pipelined(mi355lz4_ctx *c, const uint8_t *framedIn, s
 
     int32_t *resPin = (int32_t *)c->pinMeta.p;
     std::vector<hipEvent_t> evIn((size_t)G), evK((size_t)G), evOut((size_t)G);
+    // input copy of group g: enqueued one group AHEAD of its kernels, because a linked decode waits on the
+    // host for its first pass (decode_device) and the copy engine should be busy meanwhile
+    auto stage_in = [&](int g) -> int {
+        const int b0 = gFirst[g], b1 = gFirst[g + 1];
+        const size_t lo = in_lo(b0), hi = in_lo(b1);
+        int rr;
+        if ((rr = evs.make(&evIn[(size_t)g])) || (rr = evs.make(&evK[(size_t)g])) || (rr = evs.make(&evOut[(size_t)g]))) return rr;
+        if (directIn) {
+            HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, framedIn + lo, hi - lo, hipMemcpyHostToDevice, c->sIn));
+        } else {
+            uint8_t *slot = (uint8_t *)c->pinIn.p + (size_t)(g & 1) * (maxIn + 16);
+            if (g >= 2) HIP_TRY(hipEventSynchronize(evIn[(size_t)g - 2]));
+            copy_pool().copy(slot, framedIn + lo, hi - lo);
+            HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, slot, hi - lo, hipMemcpyHostToDevice, c->sIn));
+        }
+        HIP_TRY(hipEventRecord(evIn[(size_t)g], c->sIn));
+        return 0;
+    };
+    if (G > 0 && (r = stage_in(0))) return r;
     for (int t = 0; t < G + 1; t++) {
         if (t < G) {                                                           // ---- stage A, group t
             const int g = t, b0 = gFirst[g], b1 = gFirst[g + 1];
-            const size_t lo = in_lo(b0), hi = in_lo(b1);
-            if ((r = evs.make(&evIn[(size_t)g])) || (r = evs.make(&evK[(size_t)g])) || (r = evs.make(&evOut[(size_t)g]))) return r;
-            if (directIn) {
-                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, framedIn + lo, hi - lo, hipMemcpyHostToDevice, c->sIn));
-            } else {
-                uint8_t *slot = (uint8_t *)c->pinIn.p + (size_t)(g & 1) * (maxIn + 16);
-                if (g >= 2) HIP_TRY(hipEventSynchronize(evIn[(size_t)g - 2]));
-                copy_pool().copy(slot, framedIn + lo, hi - lo);
-                HIP_TRY(hipMemcpyAsync((uint8_t *)c->in.p + lo, slot, hi - lo, hipMemcpyHostToDevice, c->sIn));
-            }
-            HIP_TRY(hipEventRecord(evIn[(size_t)g], c->sIn));
+            if (linked && g + 1 < G && (r = stage_in(g + 1))) return r;
             HIP_TRY(hipStreamWaitEvent(c->stream, evIn[(size_t)g], 0));
             // the group's blocks, with the whole framed buffer as bounds and the blocks before it as look-back
             r = decode_device(c, (const uint8_t *)c->in.p, inLen, (const uint64_t *)c->offA.p + b0, b1 - b0, headerKind,
@@ -1124,6 +1133,7 @@ static int decompress_host_pipelined(mi355lz4_ctx *c, const uint8_t *framedIn, s
             if (!directOut && ohi > olo)
                 copy_pool().copy(out + olo, (const uint8_t *)c->pinOut.p + (size_t)(g & 1) * (maxOut + 16), ohi - olo);
         }
+        if (!linked && t + 1 < G && (r = stage_in(t + 1))) return r;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
 

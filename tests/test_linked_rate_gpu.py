@@ -152,3 +152,43 @@ def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks, repeat)
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
+
+
+@pytest.mark.parametrize("linked", [0, 1])
+def test_single_linked_stream_host_api_rate(engine, slz4, oracle, linked):
+    """The same kind of stream through the host-buffer call (page-locked caller memory, PCIe-inclusive):
+    the call is cut into groups, and the second pass of a group looks back into the groups before it.
+    linked = 0 on the engine's own independent blocks of the same data is the yardstick."""
+    import ctypes as C
+    import time
+    import torch
+    bl, nb0, repeat = 65536, 1024, 8
+    data = oracle.gen("text", nb0, bl, first_block=7).tobytes()
+    if linked:
+        fr = oracle.frame_compress(data, bl, 1, 8, True) * repeat
+    else:
+        blocks = [data[i * bl:(i + 1) * bl] for i in range(nb0)]
+        fr = engine.compress_batch(blocks)[0] * repeat
+    data = data * repeat
+    nb = nb0 * repeat
+    u8p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    framed_t = torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).pin_memory()
+    out_t = torch.empty(nb * bl, dtype=torch.uint8).pin_memory()
+    framed, out = framed_t.numpy(), out_t.numpy()
+    blen = np.zeros(nb, dtype=np.int32)
+    dlen, got = C.c_size_t(), C.c_int()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = slz4.lib.mi355lz4_decompress_batch(engine.ctx, framed.ctypes.data_as(u8p), framed.size, 8, 0, linked, None, 0,
+                                                out.ctypes.data_as(u8p), out.size, C.byref(dlen), blen.ctypes.data_as(i32p),
+                                                nb, C.byref(got))
+        best = min(best, time.perf_counter() - t0)
+        assert rc == 0 and dlen.value == nb * bl and got.value == nb, slz4.lib.mi355lz4_last_error()
+    assert out.tobytes() == data
+    rec = {"api": "host-buffer C API, page-locked caller memory", "streams": 1, "blocks_per_stream": nb, "block_len": bl,
+           "data": "text, " + ("reference-linked" if linked else "independent blocks (this engine's)"), "linked": linked,
+           "ms": round(best * 1e3, 3), "GBps_uncompressed": round(nb * bl / best / 1e9, 3)}
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)
