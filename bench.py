@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default: workload's)")
     ap.add_argument("--decoder", type=int, default=0, help="0 auto, 1 sequence-at-a-time, 2 lane-parallel")
     ap.add_argument("--linked", action="store_true", help="decode with linked = 1 (reference stream semantics)")
+    ap.add_argument("--linked-compress", action="store_true",
+                    help="compress this rank's blocks as ONE linked stream (previous block = dictionary, like the "
+                         "reference's compressor) and decode it with linked = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the multi-threaded best-case CPU figure")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0)
@@ -189,6 +192,11 @@ def main():
         NB = args.blocks
     eng = S.Engine(dev_index)
     eng.set_decoder(args.decoder)
+    if args.linked_compress:
+        eng.set_linked_compress(True)
+        args.linked = True
+        args.no_gather = True           # interleaving the ranks' streams would break the links
+        args.no_host_api = True
 
     # ---- setup (untimed): this rank's blocks on the device, compressed and compacted ----
     U = NB * BL
@@ -402,8 +410,10 @@ def main():
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": data_name,
-        "config": {"workload": "%s: %s, %d KiB blocks, %d blocks (%.2f GiB) per GPU, %s, accel %d, independent blocks, "
+        "config": {"workload": "%s: %s, %d KiB blocks, %d blocks (%.2f GiB) per GPU, %s, accel %d, %s, "
                                "round-robin block->GPU%s" % (args.workload, phase, BL >> 10, NB, U / 2 ** 30, kind, accel,
+                                                             "ONE LINKED stream per GPU (previous block = dictionary)"
+                                                             if args.linked_compress else "independent blocks",
                                                              ", linked=1" if args.linked else ""),
                    "block_len": BL, "blocks_per_gpu": NB, "ratio": round(U / Cbytes, 4), "decoder": args.decoder},
         "roofline": roofline,

@@ -79,6 +79,12 @@ int mi355lz4_synchronize(mi355lz4_ctx *ctx);
 /* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel,
  * 2 = lane-parallel kernel.  Tuning/ablation knob; results are identical. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
+/* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block
+ * i-1 as block i's dictionary whenever it lies directly in front of it in memory -- what the reference's
+ * LZ4_compress_fast_continue does with the previous chunk (cbits/lz4.c:1608-1636, kept alive by
+ * Internal/LZ4.hs:376,389).  The output is then a LINKED stream like the reference's (+6 % ratio on text);
+ * it must be decoded with linked != 0, in order.  Default off: independent blocks (they shard). */
+int mi355lz4_set_linked_compress(mi355lz4_ctx *ctx, int on);
 
 /* = LZ4_compressBound (cbits/lz4.c:674, lz4.h:171): n + n/255 + 16, 0 if n too large */
 int mi355lz4_compress_bound(int n);

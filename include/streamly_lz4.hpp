@@ -63,6 +63,10 @@ public:
     mi355lz4_ctx *ctx() const { return ctx_; }
     size_t batchBlocks() const { return batch_; }
     void setBatchBlocks(size_t n) { batch_ = n ? n : 1; }
+    // compressChunks then writes a LINKED stream like the reference's (each block's dictionary is the block before it
+    // within a batch; Internal/LZ4.hs:376,389 keeps the previous chunk alive for exactly this); decompressChunks
+    // reads either kind.  Default off: independent blocks.
+    void setLinkedCompress(bool on);
 private:
     mi355lz4_ctx *ctx_ = nullptr;
     size_t batch_;

@@ -4,8 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "streamly-lz4_amd"))
 import torch, streamly_lz4_amd as S
 kind = sys.argv[1] if len(sys.argv) > 1 else "lzsynth"
+linked = len(sys.argv) > 2 and sys.argv[2] == "linked"
 NB = 8192; BL = 65536
-dev = torch.device("cuda:0"); eng = S.Engine(0)
+dev = torch.device("cuda:0"); eng = S.Engine(0); eng.set_linked_compress(linked)
 S.lib.mi355lz4_debug_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
 src = torch.empty(NB * BL, dtype=torch.uint8, device=dev); eng.generate(kind, src, BL, NB)
 stride = S.slot_stride(BL, 8)
@@ -16,4 +17,4 @@ eng.compress_batch_device(src, NB, BL, slots, stride, flen); eng.synchronize()
 S.lib.mi355lz4_debug_stats(eng.ctx, 0, buf)
 v = list(buf)[:8]; w = max(v[6], 1)
 names = ["probe(v8,hash,table)", "head cand+extend", "select", "table insert+end2", "catch-up", "emit", "windows", "heads"]
-print(kind, "windows/block %.0f" % (w / NB), " cycles/window:", {n: round(x / w) for n, x in zip(names, v) if n != "windows"})
+print(kind, "linked" if linked else "independent", "windows/block %.0f" % (w / NB), " cycles/window:", {n: round(x / w) for n, x in zip(names, v) if n != "windows"})

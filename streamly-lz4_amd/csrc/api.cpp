@@ -148,6 +148,7 @@ struct mi355lz4_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int decoder = 0;
+    int linkedCompress = 0;                 // compress calls treat their blocks as consecutive blocks of one stream
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
     DevBuf tolPool, tolMeta;                // deferred-copy decode of a long linked stream (linked_replay.hpp)
@@ -333,6 +334,13 @@ extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
     return MI355LZ4_OK;
 }
 
+extern "C" int mi355lz4_set_linked_compress(mi355lz4_ctx *c, int on)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    c->linkedCompress = on ? 1 : 0;
+    return MI355LZ4_OK;
+}
+
 // Diagnostic hook (not part of the public header): enable/read the lane-parallel decoder's
 // phase counters.  enable != 0 switches the STATS kernel on (slower); out receives and resets
 // PAR_STATS_COUNT counters.
@@ -399,10 +407,9 @@ static int check_launch(const char *what)
 // ---------------------------------------------------------------------------
 // device-resident batched API
 // ---------------------------------------------------------------------------
-extern "C" int mi355lz4_compress_batch_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *srcOff,
-                                              const int32_t *srcLen, uint64_t blockStride, int maxBlockLen,
-                                              int nBlocks, int accel, int headerKind, uint8_t *slots,
-                                              size_t slotStride, int32_t *framedLen)
+static int encode_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                         uint64_t blockStride, int maxBlockLen, int nBlocks, int accel, int headerKind, uint8_t *slots,
+                         size_t slotStride, int32_t *framedLen, int lookBack)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
     if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || maxBlockLen < 0 ||
@@ -421,8 +428,18 @@ extern "C" int mi355lz4_compress_batch_device(mi355lz4_ctx *c, const uint8_t *sr
     a.uniformLen = maxBlockLen; a.nBlocks = nBlocks; a.accel = accel; a.headerKind = headerKind;
     a.slots = slots; a.slotStride = slotStride; a.framedLen = framedLen;
     a.stats = c->stats;
+    a.linked = c->linkedCompress; a.lookBack = lookBack;
     launch_encode(a, maxBlockLen > 65536, c->stream);
     return check_launch("encode launch");
+}
+
+extern "C" int mi355lz4_compress_batch_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *srcOff,
+                                              const int32_t *srcLen, uint64_t blockStride, int maxBlockLen,
+                                              int nBlocks, int accel, int headerKind, uint8_t *slots,
+                                              size_t slotStride, int32_t *framedLen)
+{
+    return encode_device(c, src, srcOff, srcLen, blockStride, maxBlockLen, nBlocks, accel, headerKind, slots, slotStride,
+                         framedLen, 0);
 }
 
 extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, size_t slotStride,
@@ -743,7 +760,8 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
         if (srcLen[i] > 0 && !src[i]) return fail(MI355LZ4_E_ARG, "compress_batch: block %d is null", i);
         offs[(size_t)i] = total;
         if (i > 0 && src[i] != src[0] + total) contiguous = false;
-        total += ((size_t)srcLen[i] + 15) & ~(size_t)15;   // 16-aligned block starts
+        // 16-aligned block starts; back to back for a linked stream (a block's dictionary lies directly in front of it)
+        total += c->linkedCompress ? (size_t)srcLen[i] : (((size_t)srcLen[i] + 15) & ~(size_t)15);
         if (srcLen[i] > maxLen) maxLen = srcLen[i];
     }
     const size_t stride = mi355lz4_slot_stride(maxLen, headerKind);
@@ -818,9 +836,10 @@ extern "C" int mi355lz4_compress_batch(mi355lz4_ctx *c, const uint8_t *const *sr
         StreamSwap on(c, c->sK[g & 1]);
         HIP_TRY(hipStreamWaitEvent(c->stream, evIn[(size_t)g], 0));
         PTRACE("compress: group %d H2D enqueued (%zu bytes, direct %d)", g, hi - lo, (int)directIn);
-        r = mi355lz4_compress_batch_device(c, (const uint8_t *)c->in.p, (const uint64_t *)c->offA.p + b0,
-                                           (const int32_t *)c->lenA.p + b0, 0, maxLen, b1 - b0, accel, headerKind,
-                                           (uint8_t *)c->slots.p + (size_t)b0 * stride, stride, (int32_t *)c->lenB.p + b0);
+        // (a linked stream: the last block of the group before is this group's first dictionary)
+        r = encode_device(c, (const uint8_t *)c->in.p, (const uint64_t *)c->offA.p + b0,
+                          (const int32_t *)c->lenA.p + b0, 0, maxLen, b1 - b0, accel, headerKind,
+                          (uint8_t *)c->slots.p + (size_t)b0 * stride, stride, (int32_t *)c->lenB.p + b0, b0);
         if (r) return r;
         uint64_t *goff = (uint64_t *)c->offB.p + b0 + g;                       // b1 - b0 + 1 offsets of this group
         r = mi355lz4_compact_device(c, (const uint8_t *)c->slots.p + (size_t)b0 * stride, stride,

@@ -89,17 +89,40 @@ __device__ __forceinline__ int enc_scan_incl(int x)
 #define ENC_LAP(i) do { } while (0)
 #endif
 
-template <typename TabT>
+// A table entry as a candidate position for `myPos`.  u32 tables hold positions; u16 tables hold their low 16
+// bits, and with a dictionary in front of the block (DICT: positions run to 128 Ki) the candidate is the
+// nearest earlier position with those bits -- at most 65535 back by construction, like the reference's window.
+template <typename TabT, bool DICT>
+__device__ __forceinline__ bool tab_candidate(TabT e, int myPos, uint32_t &cand)
+{
+    if (DICT && sizeof(TabT) == 2) {
+        const uint32_t d = ((uint32_t)myPos - (uint32_t)e) & 0xffffu;
+        cand = (uint32_t)myPos - d;
+        return d != 0u && d <= (uint32_t)myPos;
+    }
+    cand = (uint32_t)e;
+    return cand < (uint32_t)myPos && (uint32_t)myPos - cand <= LZ4_MAXDIST;   // :1003-1006
+}
+
+// DICT: the block is compressed with the dictLen bytes in front of it as its dictionary -- the previous block of
+// the stream, which LZ4_compress_fast_continue keeps as the window (cbits/lz4.c:1608-1636, kept alive by
+// Internal/LZ4.hs:376,389).  All positions are then relative to src - dictLen; the table is seeded with the
+// dictionary's positions instead of inheriting the previous call's table, which needs no order between blocks.
+template <typename TabT, bool DICT = false>
 __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int accel, TabT *table,
-                                 unsigned long long *stats = nullptr)
+                                 unsigned long long *stats = nullptr, int dictLen = 0)
 {
     const int lane = lane_id();
+    if (!DICT) dictLen = 0;
+    const int blockLen = n;
+    src -= dictLen;                      // position 0 is the first byte of the dictionary
+    n += dictLen;
 #ifdef ENC_STATS
     unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long etm = __builtin_amdgcn_s_memtime();
 #endif
     uint8_t *op = dst;
-    int anchor = 0;
+    int anchor = dictLen;
 
     // Sequence queue: selected sequences are parked one per lane (registers only) and written out
     // 64 at a time, so the emission code (:1022-1046, :1065-1135) runs with every lane busy instead of
@@ -175,7 +198,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         qCnt = 0;
     };
 
-    if (n == 0) {                       // cbits/lz4.c:1263-1273: empty input -> single 0 token
+    if (blockLen == 0) {                // cbits/lz4.c:1263-1273: empty input -> single 0 token
         if (lane == 0) dst[0] = 0;
         return 1;
     }
@@ -187,13 +210,32 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         for (int i = lane; i < nd; i += LZ4_WAVE) t32[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (DICT && blockLen >= 13) {
+        // seed: every position of the dictionary, in order (a later position replaces an earlier one); the
+        // 8 bytes behind a position near its end run into the block itself
+        // (the LDS executes one wave's stores in order: no fence between them)
+        for (int q0 = 0; q0 < dictLen; q0 += 8 * LZ4_WAVE) {
+            uint64_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + k * LZ4_WAVE + lane;
+                v[k] = (q < dictLen) ? *(const u64_unaligned *)(src + q) : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int q = q0 + k * LZ4_WAVE + lane;
+                if (q < dictLen) table[hash5(v[k])] = (TabT)q;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 
-    if (n >= 13) {                                      // LZ4_minLength, :221,:921
+    if (blockLen >= 13) {                               // LZ4_minLength, :221,:921
         const int mfl = n - LZ4_MFLIMIT + 1;            // match start must be < mfl (:883)
         const int matchlimit = n - LZ4_LASTLITERALS;    // match end must be <= matchlimit (:884)
         const uint32_t miss0 = (uint32_t)accel << 6;
         uint32_t missAcc = miss0;
-        int64_t p = 0;
+        int64_t p = dictLen;
         uint64_t pfV8 = 0;          // dense path: this lane's 8 bytes of the window that starts at pfPos
         int pfPos = -1;
 
@@ -211,8 +253,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 if (valid) {
                     v8 = (pfPos == p0) ? pfV8 : *(const u64_unaligned *)(src + myPos);
                     h = hash5(v8);
-                    cand = (uint32_t)table[h];
-                    candOk = cand < (uint32_t)myPos && (uint32_t)myPos - cand <= LZ4_MAXDIST;   // :1003-1006
+                    candOk = tab_candidate<TabT, DICT>(table[h], myPos, cand);   // :1003-1006
                 }
                 ENC_LAP(0);
                 // Candidates of neighbouring positions that are themselves neighbours (cand[l] == cand[l-1]+1)
@@ -380,8 +421,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             if (valid) {
                 v8 = *(const u64_unaligned *)(src + myPos);
                 h = hash5(v8);
-                cand = (uint32_t)table[h];
-                if (cand < (uint32_t)myPos && (uint32_t)myPos - cand <= LZ4_MAXDIST)
+                if (tab_candidate<TabT, DICT>(table[h], myPos, cand))
                     hit = (*(const u32_unaligned *)(src + cand) == (uint32_t)v8);
             }
             const uint64_t m = __ballot(hit);

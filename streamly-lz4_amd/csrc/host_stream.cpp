@@ -76,6 +76,8 @@ Engine::Engine(int device, size_t batchBlocks) : batch_(batchBlocks ? batchBlock
     if (mi355lz4_create(&ctx_, device) != MI355LZ4_OK)
         throw Error(std::string("streamly_lz4::Engine: ") + mi355lz4_last_error());
 }
+void Engine::setLinkedCompress(bool on) { mi355lz4_set_linked_compress(ctx_, on ? 1 : 0); }
+
 Engine::~Engine() { mi355lz4_destroy(ctx_); }
 
 // ---------------------------------------------------------------------------

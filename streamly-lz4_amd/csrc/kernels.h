@@ -60,6 +60,8 @@ struct EncodeArgs {
     size_t slotStride;
     int32_t *framedLen;
     unsigned long long *stats;   // diagnostics only (ENC_STATS builds); may be null
+    int linked;                  // the blocks are consecutive blocks of ONE stream: block i-1 is block i's dictionary
+    int lookBack;                // linked: blocks of the same stream that precede block 0 in srcOff[] / srcLen[]
 };
 
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);

@@ -80,7 +80,7 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // K2: encode
 // ---------------------------------------------------------------------------
-template <typename TabT>
+template <typename TabT, bool DICT>
 __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
 {
     __shared__ TabT table[4096];
@@ -88,9 +88,16 @@ __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
     const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
     const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
     uint8_t *slot = a.slots + (size_t)blk * a.slotStride;
+    int dictLen = 0;
+    if (DICT && (blk > 0 || a.lookBack > 0)) {
+        // linked stream: the block before is the dictionary when it lies directly in front of this one
+        const uint64_t poff = a.srcOff ? a.srcOff[blk - 1] : (uint64_t)(blk - 1) * a.blockStride;
+        const int pn = a.srcLen ? a.srcLen[blk - 1] : a.uniformLen;
+        if (pn > 0 && poff + (uint64_t)pn == off) dictLen = min(pn, 65536);
+    }
     int c = 0;
     if (n >= 0 && (sizeof(TabT) == 4 || n <= 65536))
-        c = encode_block_wave<TabT>(a.src + off, n, slot + a.headerKind, a.accel, table, a.stats);
+        c = encode_block_wave<TabT, DICT>(a.src + off, n, slot + a.headerKind, a.accel, table, a.stats, dictLen);
     if (lane_id() == 0) {
         store_le32(slot, c);                                   // Internal/LZ4.hs:262
         if (a.headerKind == 8) store_le32(slot + 4, n);        // Internal/LZ4.hs:261
@@ -101,10 +108,14 @@ __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
 void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s)
 {
     if (a.nBlocks <= 0) return;
-    if (wideTable)
-        hipLaunchKernelGGL(k_encode<uint32_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_encode<uint16_t>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
+    const dim3 grid((unsigned)a.nBlocks), wg(64);
+    if (a.linked) {
+        if (wideTable) hipLaunchKernelGGL((k_encode<uint32_t, true>), grid, wg, 0, s, a);
+        else hipLaunchKernelGGL((k_encode<uint16_t, true>), grid, wg, 0, s, a);
+    } else {
+        if (wideTable) hipLaunchKernelGGL((k_encode<uint32_t, false>), grid, wg, 0, s, a);
+        else hipLaunchKernelGGL((k_encode<uint16_t, false>), grid, wg, 0, s, a);
+    }
 }
 
 // ---------------------------------------------------------------------------

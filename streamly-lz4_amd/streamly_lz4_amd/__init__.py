@@ -78,6 +78,7 @@ def _load():
     sig("mi355lz4_get_stream", vp, vp)
     sig("mi355lz4_synchronize", C.c_int, vp)
     sig("mi355lz4_set_decoder", C.c_int, vp, C.c_int)
+    sig("mi355lz4_set_linked_compress", C.c_int, vp, C.c_int)
     sig("mi355lz4_compress_bound", C.c_int, C.c_int)
     sig("mi355lz4_slot_stride", C.c_size_t, C.c_int, C.c_int)
     sig("mi355lz4_compress_batch_device", C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -139,7 +140,7 @@ lib = _load()
 # every symbol include/mi355lz4.h and include/lz4.h declare (checked by tests without a GPU)
 DECLARED_SYMBOLS = [
     "mi355lz4_version", "mi355lz4_last_error", "mi355lz4_device_count", "mi355lz4_create", "mi355lz4_destroy",
-    "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder",
+    "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder", "mi355lz4_set_linked_compress",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
     "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
     "mi355lz4_decompress_batch", "mi355lz4_decompress_streams", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
@@ -281,6 +282,10 @@ class Engine:
 
     def set_decoder(self, variant):
         _check(lib.mi355lz4_set_decoder(self.ctx, int(variant)), "set_decoder")
+
+    def set_linked_compress(self, on):
+        """Compress calls write ONE linked stream (previous block = dictionary), like the reference's compressor."""
+        _check(lib.mi355lz4_set_linked_compress(self.ctx, int(bool(on))), "set_linked_compress")
 
     def use_stream(self, hip_stream):
         """Pin the engine to one caller-owned hipStream_t (stops following torch's current stream)."""

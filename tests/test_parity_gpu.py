@@ -200,6 +200,67 @@ def test_encode_size_vs_reference(engine, oracle):
                 assert ours <= ref * tol, (kind, bl, accel, ours, ref)
 
 
+def test_linked_compress(engine, oracle):
+    """Linked compression (mi355lz4_set_linked_compress: block i-1 is block i's dictionary, what the reference's
+    LZ4_compress_fast_continue does with the previous chunk, cbits/lz4.c:1608-1636): the stream decodes through the
+    oracle's LINKED decoder and through the GPU's (linked = 1) to the input, its blocks really reach into their
+    predecessors, and its size is the reference's linked size within the tolerance of the independent case --
+    i.e. the +6 % an independent-block stream gives away on text is gone."""
+    rng = random.Random(31)
+    try:
+        for kind, tol in (("text", 1.06), ("lzsynth", 1.04)):
+            for bl, n in ((65536, 12), (16384, 9), (262144, 3)):
+                data = oracle.gen(kind, n, bl, first_block=77).tobytes()
+                blocks = [data[i * bl:(i + 1) * bl] for i in range(n)]
+                engine.set_linked_compress(False)
+                indep = engine.compress_batch(blocks)[0]
+                engine.set_linked_compress(True)
+                fr, flen = engine.compress_batch(blocks)
+                assert oracle.frame_decompress(fr, n * bl, 8, 0, True) == data
+                out, blen = engine.decompress_batch(fr, linked=True)
+                assert out == data and blen == [bl] * n
+                ref = len(oracle.frame_compress(data, bl, 1, 8, True))
+                assert len(fr) <= ref * tol, (kind, bl, len(fr), ref)
+                if kind == "text":
+                    # the dictionary pays (less so when a block is four windows long)
+                    assert len(fr) < len(indep) * (0.985 if bl <= 65536 else 1.0), (bl, len(fr), len(indep))
+                    print("linked compress, text, %d-byte blocks: %d bytes; independent %d; reference linked %d"
+                          % (bl, len(fr), len(indep), ref))
+                    _, standalone = engine.decompress_batch(fr, linked=False, raise_on_block_error=False)
+                    assert standalone[0] == bl and sum(1 for r in standalone[1:] if r < 0) >= n // 2
+        # the stream combinators over the same switch: compressChunks writes the linked stream, decompressChunks reads it
+        import streamly_lz4_amd as S
+        data = oracle.gen("text", 40, 32768, first_block=3).tobytes()
+        arrays = [data[i * 32768:(i + 1) * 32768] for i in range(40)]
+        cfg = S.defaultBlockConfig
+        linked_arrays = S.compressChunks(cfg, 1, arrays, engine)
+        assert b"".join(S.decompressChunks(cfg, linked_arrays, engine)) == data
+        engine.set_linked_compress(False)
+        indep_arrays = S.compressChunks(cfg, 1, arrays, engine)
+        engine.set_linked_compress(True)
+        assert sum(map(len, linked_arrays)) < 0.95 * sum(map(len, indep_arrays))
+        # ragged blocks (a short block is a short dictionary; an empty one is none), and a block above 64 KiB
+        sizes = [65536, 1000, 65536, 0, 13, 12, 40000, 70000, 65536, 5]
+        data = oracle.gen("text", 8, 65536, first_block=5).tobytes()
+        blocks, pos = [], 0
+        for sz in sizes:
+            blocks.append(data[pos:pos + sz])
+            pos += sz
+        fr, flen = engine.compress_batch(blocks)
+        out, blen = engine.decompress_batch(fr, linked=True)
+        assert blen == sizes and out == data[:pos]
+        # the oracle's linked decoder, block by block, with the previous non-empty block as dictionary
+        dict_bytes, o = None, 0
+        for b, sz in zip(split_blocks(fr), sizes):
+            code, dec = oracle.decompress_block(b[8:], sz, dict_bytes)
+            assert code == sz and dec == data[o:o + sz]
+            o += sz
+            if code > 0:
+                dict_bytes = dec
+    finally:
+        engine.set_linked_compress(False)
+
+
 def test_compact_honours_dense_cap(engine, slz4, oracle):
     """mi355lz4_compact_device never writes at or past denseCap: blocks that do not fit are skipped and
     denseOff[nBlocks] still reports the bytes the whole stream needs."""
