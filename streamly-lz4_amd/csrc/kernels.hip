@@ -669,19 +669,41 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
     if (__syncthreads_or(bad ? 1 : 0)) fail();
 }
 
+// Workgroup -> (block of the segment, part of the block) for the jump and fetch passes.  Workgroups go to the 8
+// XCDs round-robin and each XCD has its own L2: a run of PTR_RUN consecutive blocks, all parts, is given to ONE
+// XCD, so that the pointers a chain visits (its own block's and the block's before) are in the L2 it runs on.
+#ifndef PTR_RUN
+#define PTR_RUN 16
+#endif
+__device__ __forceinline__ void ptr_map(unsigned wg, int &blkRel, int &part)
+{
+#ifdef PTR_FLAT_MAP
+    blkRel = (int)(wg / PTR_PARTS); part = (int)(wg % PTR_PARTS);
+#else
+    const unsigned xcd = wg & 7u, j = wg >> 3;                      // the j-th workgroup this XCD receives
+    const unsigned per = PTR_RUN * PTR_PARTS;
+    const unsigned run = j / per, within = j % per;
+    blkRel = (int)((run * 8u + xcd) * PTR_RUN + within / PTR_PARTS);
+    part = (int)(within % PTR_PARTS);
+#endif
+}
+static unsigned ptr_grid(int n) { return (unsigned)((n + 8 * PTR_RUN - 1) / (8 * PTR_RUN)) * (8 * PTR_RUN) * PTR_PARTS; }
+
 // One pass of pointer jumping over the bytes of the listed blocks (PTR_PARTS workgroups per block).  Reads of
 // pointers another thread is updating are harmless: every value a pointer ever holds is an ancestor.
 __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
 {
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     if (pass > 0 && !ctl->changed[pass - 1]) return;
-    const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
-    if (!ptr_taken(a, blk)) return;
+    int blkRel, part;
+    ptr_map(blockIdx.x, blkRel, part);
+    const int blk = a.segFirst + blkRel;
+    if (blk >= a.segEnd || !ptr_taken(a, blk)) return;
     uint32_t *P = a.ptr;
     const uint32_t bLo = (uint32_t)(a.outOff[blk] - ptr_lo(a) + PTR_PRE);
     const int size = a.tolSize[blk];
     const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
-    const int x0 = (int)(blockIdx.x % PTR_PARTS) * per, x1 = min(size, x0 + per);
+    const int x0 = part * per, x1 = min(size, x0 + per);
     bool open = false;
     auto chase = [&](uint32_t e) -> uint32_t {
 #pragma unroll
@@ -727,14 +749,15 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
 // Every deferred byte is fetched from its root; the block's result becomes its size.
 __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
 {
-    const int blk = a.segFirst + (int)(blockIdx.x / PTR_PARTS);
-    if (!ptr_taken(a, blk)) return;
+    int blkRel, part;
+    ptr_map(blockIdx.x, blkRel, part);
+    const int blk = a.segFirst + blkRel;
+    if (blk >= a.segEnd || !ptr_taken(a, blk)) return;
     const uint32_t *P = a.ptr;
     const uint64_t lo = ptr_lo(a);
     const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
     const int size = a.tolSize[blk];
     const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
-    const int part = (int)(blockIdx.x % PTR_PARTS);
     const int x0 = part * per, x1 = min(size, x0 + per);
     uint8_t *dst = a.out + a.outOff[blk];
     const uint8_t *outLo = a.out + lo;
@@ -816,8 +839,8 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
         hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
         hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
         for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
-            hipLaunchKernelGGL(k_ptr_jump, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a, pass);
-        hipLaunchKernelGGL(k_ptr_fetch, dim3((unsigned)n * PTR_PARTS), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_ptr_jump, dim3(ptr_grid(n)), dim3(256), 0, s, a, pass);
+        hipLaunchKernelGGL(k_ptr_fetch, dim3(ptr_grid(n)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     }
     // whatever the pass above did not take (ptrBad, or no pool): the walk, block after block

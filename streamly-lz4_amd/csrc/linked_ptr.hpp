@@ -29,9 +29,24 @@ namespace lz4dev {
 
 #define PTR_FINAL 0x80000000u
 #define PTR_PRE 65536u
-#define PTR_JUMPS 3                // dependent jumps per pass: the depth shrinks 8-fold per launch
-#define PTR_MAX_PASSES 12          // 8^11 > 2^31 pointers
-#define PTR_PARTS 4                // workgroups per block in the jump / fetch passes
+// A pass follows up to PTR_JUMPS + 1 pointers from every unresolved byte and stores where it got to.  If every
+// pointer spans at least s levels of its chain before a pass, it spans at least (PTR_JUMPS + 1) * s after it
+// (each hop reads a pointer that is at least as good as before the pass), so k passes resolve every chain of
+// depth < (PTR_JUMPS + 1)^k, whatever other threads have or have not written meanwhile.  A segment holds fewer
+// than 2^31 pointers: PTR_MAX_PASSES passes always suffice, and the ones that find nothing to do cost 6 us each.
+#ifndef PTR_JUMPS
+#define PTR_JUMPS 11
+#endif
+constexpr int ptr_passes_for(int jumps)
+{
+    int k = 0;
+    for (unsigned long long span = 1; span < (1ull << 31); span *= (unsigned long long)(jumps + 1)) k++;
+    return k + 1;                      // + the pass that sees that nothing is left
+}
+#define PTR_MAX_PASSES (ptr_passes_for(PTR_JUMPS))
+#ifndef PTR_PARTS
+#define PTR_PARTS 16               // workgroups per block in the jump / fetch passes
+#endif
 
 struct PtrCtl {
     uint32_t changed[PTR_MAX_PASSES + 1];   // pass r left unresolved pointers behind

@@ -761,6 +761,27 @@ def test_single_linked_stream_fuzz_codes(engine, oracle, linked_variant):
             o += ulen[j]
 
 
+def test_single_linked_stream_deep_chains(engine, oracle, linked_variant):
+    """Streams in which a byte's origin lies arbitrarily far back: runs (every byte copies the one before it, across
+    every block seam: a chain as deep as the stream is long), short and long periods, a period longer than a block.
+    The pointer pass resolves a chain of depth d in log(d) passes; the other paths walk it."""
+    bl = 65536
+    cases = {
+        "zeros": bytes(40 * bl),
+        "period 3": (b"abc" * (14 * bl // 3 + 1))[: 14 * bl],
+        "period 70001": (oracle.gen("text", 2, bl, first_block=9).tobytes()[:70001] * 12)[: 11 * bl],
+        "runs in text": b"".join(oracle.gen("text", 1, bl, first_block=i).tobytes()[:3000] + bytes([65 + i]) * 20000 for i in range(30)),
+    }
+    for name, d in cases.items():
+        d = d[: len(d) // bl * bl]
+        fr = oracle.frame_compress(d, bl, 1, 8, True)
+        out, res, ulen, _ = _decode_streams(engine, [fr], "one")
+        assert res == ulen and out == d, name
+        # the same stream as two streams of a multi-stream call (the second starts without a dictionary)
+        out, res, ulen, _ = _decode_streams(engine, [fr, fr], "streams")
+        assert res == ulen and out == d + d, name
+
+
 def test_linked_streams_host_api(engine, oracle):
     """mi355lz4_decompress_streams (host buffers) == the device entry point == the raw data."""
     datas, frs = [], []
