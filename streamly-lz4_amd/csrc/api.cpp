@@ -509,10 +509,10 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     const bool usePtr = !envPtr || atoi(envPtr) != 0;
     // Many short streams are walked side by side, one wavefront per stream, faster than their bytes are resolved
     // through pointers: a walk costs ~0.42 ms per dependent block of the longest stream (up to ~5000 streams at a
-    // time), the pointer passes ~0.6 ms + 1.4 us per dependent block of the call (MI355X, text-like data).
+    // time), the pointer passes ~0.55 ms + 1.15 us per dependent block of the call (MI355X, text-like data).
     const bool walkStreams = streamFirst && !getenv("MI355LZ4_LINKED_PTR") &&
                              0.42 * (double)(stat[3] > 0 ? stat[3] - 1 : 0) * (double)(1 + nStreams / 5000) <
-                                 0.6 + 1.4e-3 * (double)stat[0];
+                                 0.55 + 1.15e-3 * (double)stat[0];
     const int span = last - first + 1;
     const int pool = (poolMax > 0 && !walkStreams) ? ((span < poolMax) ? span : poolMax) : span;
     int seg = pool;

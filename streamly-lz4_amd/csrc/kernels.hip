@@ -9,6 +9,8 @@
 // Everything is HBM/LDS byte work; there is deliberately no MFMA anywhere.
 #include "kernels.h"
 
+#include <algorithm>
+
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
 #include "linked_replay.hpp"
@@ -691,20 +693,24 @@ static unsigned ptr_grid(int n) { return (unsigned)((n + 8 * PTR_RUN - 1) / (8 *
 
 // One pass of pointer jumping over the bytes of the listed blocks (PTR_PARTS workgroups per block).  Reads of
 // pointers another thread is updating are harmless: every value a pointer ever holds is an ancestor.
-__global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
+__global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsigned items)
 {
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     if (pass > 0 && !ctl->changed[pass - 1]) return;
-    int blkRel, part;
-    ptr_map(blockIdx.x, blkRel, part);
-    const int blk = a.segFirst + blkRel;
-    if (blk >= a.segEnd || !ptr_taken(a, blk)) return;
     uint32_t *P = a.ptr;
+    bool open = false;
+    int lastBlk = -1;
+    // (passes behind the first are launched with a small grid: they usually find nothing to do)
+    for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    int blkRel, part;
+    ptr_map(item, blkRel, part);
+    const int blk = a.segFirst + blkRel;
+    if (blk >= a.segEnd || !ptr_taken(a, blk)) continue;
+    lastBlk = blk;
     const uint32_t bLo = (uint32_t)(a.outOff[blk] - ptr_lo(a) + PTR_PRE);
     const int size = a.tolSize[blk];
     const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
     const int x0 = part * per, x1 = min(size, x0 + per);
-    bool open = false;
     auto chase = [&](uint32_t e) -> uint32_t {
 #pragma unroll
         for (int k = 0; k < PTR_JUMPS; k++) {
@@ -715,16 +721,29 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
         return e;
     };
     if (((bLo | (uint32_t)x0) & 3u) == 0) {
-        // four pointers per thread (16-byte accesses); the four chains are independent loads in flight
+        // four pointers per thread (16-byte accesses)
         uint4 *P4 = (uint4 *)(P + bLo);
         const int q1 = x1 >> 2;
         for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
             uint4 v = P4[q];
             if ((v.x & v.y & v.z & v.w) & PTR_FINAL) continue;
-            if (!(v.x & PTR_FINAL)) v.x = chase(v.x);
-            if (!(v.y & PTR_FINAL)) v.y = chase(v.y);
-            if (!(v.z & PTR_FINAL)) v.z = chase(v.z);
-            if (!(v.w & PTR_FINAL)) v.w = chase(v.w);
+            // One hop for all four per step.  Neighbouring bytes of a match have neighbouring sources, hop after hop,
+            // until a chain leaves its match: while the four pointers are consecutive they are fetched with ONE
+            // 16-byte request; otherwise with up to four requests that are in flight together.
+#pragma unroll 1
+            for (int k = 0; k <= PTR_JUMPS; k++) {
+                const bool o0 = !(v.x & PTR_FINAL), o1 = !(v.y & PTR_FINAL), o2 = !(v.z & PTR_FINAL), o3 = !(v.w & PTR_FINAL);
+                if (!(o0 || o1 || o2 || o3)) break;
+                if (k == PTR_JUMPS) { open = true; break; }
+                if (o0 && o1 && o2 && o3 && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
+                    uint4 w;
+                    __builtin_memcpy(&w, P + v.x, 16);
+                    v = w;
+                } else {
+                    const uint32_t n0 = o0 ? P[v.x] : v.x, n1 = o1 ? P[v.y] : v.y, n2 = o2 ? P[v.z] : v.z, n3 = o3 ? P[v.w] : v.w;
+                    v.x = n0; v.y = n1; v.z = n2; v.w = n3;
+                }
+            }
             P4[q] = v;
         }
         for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
@@ -737,11 +756,12 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass)
             if (!(e & PTR_FINAL)) P[bLo + (uint32_t)x] = chase(e);
         }
     }
+    }
     if (__syncthreads_or(open ? 1 : 0) && threadIdx.x == 0) {
         ctl->changed[pass] = 1u;
-        if (pass == PTR_MAX_PASSES - 1) {                  // cannot happen (8^passes > pointers); never guess
+        if (pass == PTR_MAX_PASSES - 1 && lastBlk >= 0) {  // cannot happen (linked_ptr.hpp); never guess
             bool hd;
-            atomicOr(&a.ptrBad[ptr_stream(a, blk, hd)], 1u);
+            atomicOr(&a.ptrBad[ptr_stream(a, lastBlk, hd)], 1u);
         }
     }
 }
@@ -776,11 +796,15 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
             const bool m0 = v.x != self, m1 = v.y != self + 1u, m2 = v.z != self + 2u, m3 = v.w != self + 3u;
             if (!(m0 || m1 || m2 || m3)) continue;
             uint32_t w;
-            __builtin_memcpy(&w, dst + 4 * q, 4);
-            if (m0) w = (w & 0xffffff00u) | (uint32_t)root(v.x);
-            if (m1) w = (w & 0xffff00ffu) | ((uint32_t)root(v.y) << 8);
-            if (m2) w = (w & 0xff00ffffu) | ((uint32_t)root(v.z) << 16);
-            if (m3) w = (w & 0x00ffffffu) | ((uint32_t)root(v.w) << 24);
+            if (m0 && m1 && m2 && m3 && v.x >= PTR_PRE && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
+                __builtin_memcpy(&w, outLo + (v.x - PTR_PRE), 4);          // four neighbouring roots: one request
+            } else {
+                __builtin_memcpy(&w, dst + 4 * q, 4);
+                if (m0) w = (w & 0xffffff00u) | (uint32_t)root(v.x);
+                if (m1) w = (w & 0xffff00ffu) | ((uint32_t)root(v.y) << 8);
+                if (m2) w = (w & 0xff00ffffu) | ((uint32_t)root(v.z) << 16);
+                if (m3) w = (w & 0x00ffffffu) | ((uint32_t)root(v.w) << 24);
+            }
             __builtin_memcpy(dst + 4 * q, &w, 4);
         }
         for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
@@ -839,7 +863,7 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
         hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
         hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
         for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
-            hipLaunchKernelGGL(k_ptr_jump, dim3(ptr_grid(n)), dim3(256), 0, s, a, pass);
+            hipLaunchKernelGGL(k_ptr_jump, dim3(pass == 0 ? ptr_grid(n) : std::min(ptr_grid(n), 4096u)), dim3(256), 0, s, a, pass, ptr_grid(n));
         hipLaunchKernelGGL(k_ptr_fetch, dim3(ptr_grid(n)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     }
