@@ -96,9 +96,10 @@ struct Lz4FrameOptions {
     bool blockChecksum = false;                         // xxh32 behind every block
     bool contentChecksum = true;                        // xxh32 of the content behind the end mark (the CLI's default)
     bool contentSize = false;                           // 8-byte content size in the descriptor
+    bool linkedBlocks = false;                          // block-dependent frame (the lz4 tool's default): smaller on text
 };
 uint32_t xxh32(const uint8_t *p, size_t len, uint32_t seed);
-// One frame, independent blocks (every block is compressed on its own: the batch is the frame).
+// One frame (all blocks in one batch; independent blocks unless opt.linkedBlocks).
 Array lz4FrameCompress(const Array &data, int speed, Engine &eng, const Lz4FrameOptions &opt = Lz4FrameOptions());
 // Host half of the reader: parses ONE frame at frame[at...] (advancing at), verifies header and block checksums and
 // re-frames the blocks for the engine ([compLen LE32][LZ4 block], stored blocks as literal-only blocks).

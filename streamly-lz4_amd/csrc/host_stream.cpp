@@ -536,14 +536,14 @@ int slz4_simple_frame_parser(const uint8_t *data, const uint64_t *lens, size_t n
 // ---- standard LZ4 frames (csrc/lz4_frame.cpp) ----
 uint32_t slz4_xxh32(const uint8_t *data, size_t len, uint32_t seed) { return xxh32(data, len, seed); }
 
-// flags: bit 0 block checksums, bit 1 content checksum, bit 2 content size
+// flags: bit 0 block checksums, bit 1 content checksum, bit 2 content size, bit 3 linked blocks
 int slz4_lz4frame_compress(slz4_engine *h, int blockSizeKind, int flags, int speed, const uint8_t *data, size_t len,
                            slz4_arrays **out)
 {
     return guarded(out, [&] {
         Lz4FrameOptions o;
         o.blockMax = cfg_from_kind(blockSizeKind).blockSize;
-        o.blockChecksum = flags & 1; o.contentChecksum = flags & 2; o.contentSize = flags & 4;
+        o.blockChecksum = flags & 1; o.contentChecksum = flags & 2; o.contentSize = flags & 4; o.linkedBlocks = flags & 8;
         std::vector<Array> v;
         v.push_back(lz4FrameCompress(Array(data, data + len), speed, *h->e, o));
         return fromList(std::move(v));

@@ -77,8 +77,10 @@ Array lz4FrameCompress(const Array &data, int speed, Engine &eng, const Lz4Frame
     const size_t bmax = bd_size(code);
     Array out;
     put32(out, 0x184D2204u);
-    const uint8_t flg = (uint8_t)(0x40 | 0x20 | (opt.blockChecksum ? 0x10 : 0) | (opt.contentSize ? 0x08 : 0) |
-                                  (opt.contentChecksum ? 0x04 : 0));            // version 01, independent blocks
+    // version 01; blocks independent, or linked (every block's dictionary is the block before it: full blocks, so
+    // that block IS the frame format's 64 KiB window -- what the lz4 tool writes by default)
+    const uint8_t flg = (uint8_t)(0x40 | (opt.linkedBlocks ? 0 : 0x20) | (opt.blockChecksum ? 0x10 : 0) |
+                                  (opt.contentSize ? 0x08 : 0) | (opt.contentChecksum ? 0x04 : 0));
     const size_t descAt = out.size();
     out.push_back(flg);
     out.push_back((uint8_t)(code << 4));
@@ -98,8 +100,10 @@ Array lz4FrameCompress(const Array &data, int speed, Engine &eng, const Lz4Frame
         }
         Array framed(cap);
         size_t outLen = 0;
+        if (opt.linkedBlocks) eng.setLinkedCompress(true);
         const int r = mi355lz4_compress_batch(eng.ctx(), ptrs.data(), lens.data(), (int)nb, speed < 0 ? 0 : speed, 4,
                                               framed.data(), cap, &outLen, flen.data(), status.data());
+        if (opt.linkedBlocks) eng.setLinkedCompress(false);
         if (r != MI355LZ4_OK) throw Error(std::string("lz4FrameCompress: ") + mi355lz4_last_error());
         size_t pos = 0;
         for (size_t i = 0; i < nb; i++) {

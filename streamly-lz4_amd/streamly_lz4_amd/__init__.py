@@ -514,11 +514,11 @@ def xxh32(data, seed=0):
 
 
 def lz4FrameCompress(data, engine, speed=1, blockMax=BlockSize.BlockMax64KB, blockChecksum=False, contentChecksum=True,
-                     contentSize=False):
-    """One standard LZ4 frame with independent blocks -- readable by LZ4F_decompress / `lz4 -d`.  The reference's
+                     contentSize=False, linkedBlocks=False):
+    """One standard LZ4 frame (independent blocks, or linked ones: smaller on text) -- readable by LZ4F_decompress / `lz4 -d`.  The reference's
     own frame support stops at parsing a header without these options (src/Streamly/Internal/LZ4.hs:631-638)."""
     a, n = _bytes_arg(data)
-    flags = (1 if blockChecksum else 0) | (2 if contentChecksum else 0) | (4 if contentSize else 0)
+    flags = (1 if blockChecksum else 0) | (2 if contentChecksum else 0) | (4 if contentSize else 0) | (8 if linkedBlocks else 0)
     return _run(lib.slz4_lz4frame_compress, engine._h, int(blockMax), flags, int(speed), a.ctypes.data_as(_u8p), n)[0]
 
 

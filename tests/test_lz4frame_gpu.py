@@ -70,6 +70,26 @@ def test_block_sizes_both_ways(eng, block_id):
 
 
 @needs_lz4f
+@pytest.mark.parametrize("block_id", [4, 5, 7])
+def test_linked_frames_written_here(eng, block_id):
+    """Block-dependent frames (what `lz4` writes by default), written with linked compression: liblz4 reads them,
+    so does this reader, and on text they are smaller than the independent-block frame of the same data."""
+    import streamly_lz4_amd as slz
+    for size in (0, 70000, 3 * (1 << 20) + 4321):
+        data = _text(size, 40 + block_id)
+        frame = slz.lz4FrameCompress(data, eng, blockMax=BLOCK_IDS[block_id], linkedBlocks=True, blockChecksum=True)
+        assert len(frame) >= 7 and not frame[4] & 0x20
+        assert lz4f.decompress(L, frame, len(data) + 16) == data
+        assert slz.lz4FrameDecompress(frame, eng) == data
+        if size > (1 << 20) and block_id == 4:
+            indep = slz.lz4FrameCompress(data, eng, blockMax=BLOCK_IDS[block_id], blockChecksum=True)
+            assert len(frame) < 0.99 * len(indep)
+    mixed = _mixed(2 * (1 << 20), 77)                       # stored blocks inside a linked frame
+    frame = slz.lz4FrameCompress(mixed, eng, linkedBlocks=True)
+    assert lz4f.decompress(L, frame, len(mixed) + 16) == mixed and slz.lz4FrameDecompress(frame, eng) == mixed
+
+
+@needs_lz4f
 @pytest.mark.parametrize("linked", [False, True])
 @pytest.mark.parametrize("size", [0, 5, 65536, 200000, 4 * (1 << 20) + 99])
 @pytest.mark.parametrize("kw", [dict(), dict(content_checksum=True, block_checksum=True), dict(level=9)])
