@@ -624,9 +624,10 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
     const uint64_t b64 = a.outOff[blk] - lo + PTR_PRE;
     if (b64 + (uint64_t)size > a.ptrCap || b64 + (uint64_t)size >= (uint64_t)PTR_FINAL) { fail(); return; }
     const uint32_t bLo = (uint32_t)b64;
-    for (uint32_t i = (uint32_t)tid; i < (uint32_t)size; i += 256u) P[bLo + i] = (bLo + i) | PTR_FINAL;
-    if (!listed) return;
-    __syncthreads();
+    if (!listed) {                                                  // a block that needed nothing: all roots
+        for (uint32_t i = (uint32_t)tid; i < (uint32_t)size; i += 256u) P[bLo + i] = (bLo + i) | PTR_FINAL;
+        return;
+    }
 
     // the dictionary in force (cbits/lz4.c:2347-2355 with every block in its own allocation): the block before
     uint32_t dictEnd = PTR_PRE;                                     // pointer index one past the dictionary
@@ -646,27 +647,51 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
     const int n = a.tolCount[blk];
     const int lane = tid & 63;
     bool bad = false;
+    auto unpack = [](uint64_t w, int &dpos, int &ml, int &spos) {
+        dpos = (int)(uint32_t)(w & 0xffffu); ml = (int)(uint32_t)((w >> 16) & 0xffffu); spos = (int)(uint32_t)(w >> 32);
+    };
+    // The list is in stream order: destinations ascend and do not overlap.  Entry e writes the pointers of ITS range
+    // of the block in one go: the clean bytes between the entry before it and itself (roots), then its own bytes.
     for (int e0 = 0; e0 < n; e0 += 256) {
         const int e = e0 + tid;
-        int dpos = 0, ml = 0, spos = 0;
+        int gs = 0, dpos = 0, ml = 0, spos = 0;
         if (e < n) {
-            const uint64_t w = *(const uint64_t *)(list + e);
-            dpos = (int)(uint32_t)(w & 0xffffu); ml = (int)(uint32_t)((w >> 16) & 0xffffu); spos = (int)(uint32_t)(w >> 32);
-            if (!(ml > 0 && spos < dpos && dpos + ml <= size && spos >= -dictLen)) bad = true;
+            unpack(*(const uint64_t *)(list + e), dpos, ml, spos);
+            if (e > 0) {
+                int pd, pm, ps;
+                unpack(*(const uint64_t *)(list + e - 1), pd, pm, ps);
+                gs = pd + pm;
+            }
+            if (!(ml > 0 && spos < dpos && dpos + ml <= size && spos >= -dictLen && gs <= dpos)) bad = true;
             // a match that starts in the dictionary must end LASTLITERALS before the end of the output (:1884-1889)
             if (spos < 0 && dpos + ml > cap - LZ4_LASTLITERALS) bad = true;
-            if (bad) ml = 0;
+            if (bad) { ml = 0; gs = dpos; }
         }
-        // byte j of the match comes from position spos + j: in this block, or (negative) in the dictionary
-        auto srcIdx = [&](int sp) -> uint32_t { return (sp >= 0) ? bLo + (uint32_t)sp : dictEnd - (uint32_t)(-sp); };
-        const int head = min(ml, 8);
-        for (int j = 0; j < head; j++) P[bLo + (uint32_t)(dpos + j)] = srcIdx(spos + j);
-        for (uint64_t lm = __ballot(ml > 8); lm; lm &= lm - 1) {   // the rest of a long match: by the whole wave
+        // position x of the range: a root in front of dpos; behind it byte x - dpos of the match, which comes from
+        // position spos + (x - dpos): in this block, or (negative) in the dictionary
+        auto ptrAt = [&](int x, int d, int sp) -> uint32_t {
+            if (x < d) return (bLo + (uint32_t)x) | PTR_FINAL;
+            const int s1 = sp + (x - d);
+            return (s1 >= 0) ? bLo + (uint32_t)s1 : dictEnd - (uint32_t)(-s1);
+        };
+        const int len = dpos + ml - gs;
+        const int head = min(len, 8);
+        for (int j = 0; j < head; j++) P[bLo + (uint32_t)(gs + j)] = ptrAt(gs + j, dpos, spos);
+        for (uint64_t lm = __ballot(len > 8); lm; lm &= lm - 1) {  // the rest of a long range: by the whole wave
             const int k = (int)__builtin_ctzll(lm);
-            const int kd = __builtin_amdgcn_readlane(dpos, k), ks = __builtin_amdgcn_readlane(spos, k);
-            const int kml = __builtin_amdgcn_readlane(ml, k);
-            for (int j = 8 + lane; j < kml; j += LZ4_WAVE) P[bLo + (uint32_t)(kd + j)] = srcIdx(ks + j);
+            const int kg = __builtin_amdgcn_readlane(gs, k), kd = __builtin_amdgcn_readlane(dpos, k);
+            const int ks = __builtin_amdgcn_readlane(spos, k), kend = kd + __builtin_amdgcn_readlane(ml, k);
+            for (int x = kg + 8 + lane; x < kend; x += LZ4_WAVE) P[bLo + (uint32_t)x] = ptrAt(x, kd, ks);
         }
+    }
+    {   // the clean bytes behind the last entry
+        int tail = 0;
+        if (n > 0) {
+            int pd, pm, ps;
+            unpack(*(const uint64_t *)(list + n - 1), pd, pm, ps);
+            tail = min(pd + pm, size);
+        }
+        for (int x = tail + tid; x < size; x += 256) P[bLo + (uint32_t)x] = (bLo + (uint32_t)x) | PTR_FINAL;
     }
     if (__syncthreads_or(bad ? 1 : 0)) fail();
 }
