@@ -7,7 +7,7 @@ import torch, streamly_lz4_amd as S
 kinds = (sys.argv[1] if len(sys.argv) > 1 else "lzsynth,text").split(",")
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 variants = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "2,3").split(",")]
-dev = torch.device("cuda:0"); eng = S.Engine(0); BL = 65536
+dev = torch.device("cuda:0"); eng = S.Engine(0); BL = int(os.environ.get("AB_BL", "65536"))
 for kind in kinds:
     src = torch.empty(NB * BL, dtype=torch.uint8, device=dev); eng.generate(kind, src, BL, NB)
     stride = S.slot_stride(BL, 8)

@@ -2,7 +2,7 @@
 24 MiB call flow through ~24 groups on the three streams.  Run in a child process because the group size is
 read once per process.  Checked against the oracle: round trip, the reference's linked stream (every block
 reaching into its predecessor, across group boundaries), blocks that decode short of their capacity, a
-corrupted block, ragged blocks, and page-locked caller buffers."""
+corrupted block, ragged blocks, page-locked caller buffers, and linked compression across group boundaries."""
 import os
 import subprocess
 import sys
@@ -74,6 +74,16 @@ assert bytes(framed.numpy()[:olen.value]) == fr                      # same byte
 assert S.lib.mi355lz4_decompress_batch(eng.ctx, C.cast(framed.data_ptr(), u8p), olen.value, 8, 0, 1, None, 0,
                                        C.cast(back.data_ptr(), u8p), n * bl, C.byref(dlen), fl.ctypes.data_as(i32p), n, C.byref(got)) == 0
 assert dlen.value == n * bl and bytes(back.numpy()) == raw
+# 8. linked compression through many groups: a group's first block has the last block of the group before as its
+#    dictionary (every block but the first reaches back), both linked decoders return the input
+eng.set_linked_compress(True)
+frl, fll = eng.compress_batch(blocks, accel=1)
+eng.set_linked_compress(False)
+assert len(frl) < 0.97 * len(fr) and O.frame_decompress(frl, n * bl, 8, 0, True) == raw
+out, blen = eng.decompress_batch(frl, linked=True)
+assert blen == [bl] * n and out == raw
+out, blen = eng.decompress_batch(frl, linked=False, raise_on_block_error=False)
+assert blen[0] == bl and sum(1 for b in blen[1:] if b < 0) >= n - 8
 print("pipeline ok")
 '''
 
