@@ -211,19 +211,23 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (DICT && blockLen >= 13) {
-        // seed: every position of the dictionary, in order (a later position replaces an earlier one); the
+        // seed: positions of the dictionary, in order (a later position replaces an earlier one); the
         // 8 bytes behind a position near its end run into the block itself
         // (the LDS executes one wave's stores in order: no fence between them)
-        for (int q0 = 0; q0 < dictLen; q0 += 8 * LZ4_WAVE) {
+#ifndef ENC_SEED_STEP
+#define ENC_SEED_STEP 2           // every second position: same size as every position (the reference's own table only
+#endif                           // holds the positions its parse visited), every fourth costs 0.3 % of size
+
+        for (int q0 = 0; q0 < dictLen; q0 += 8 * LZ4_WAVE * ENC_SEED_STEP) {
             uint64_t v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int q = q0 + k * LZ4_WAVE + lane;
+                const int q = q0 + (k * LZ4_WAVE + lane) * ENC_SEED_STEP;
                 v[k] = (q < dictLen) ? *(const u64_unaligned *)(src + q) : 0ull;
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int q = q0 + k * LZ4_WAVE + lane;
+                const int q = q0 + (k * LZ4_WAVE + lane) * ENC_SEED_STEP;
                 if (q < dictLen) table[hash5(v[k])] = (TabT)q;
             }
         }
