@@ -21,13 +21,16 @@
 -- Design: the incoming @Array Word8@ stream is grouped into batches of up to
 -- 'batchBlocks' arrays; one @ccall safe@ hands a batch to the GPU (a GPU round trip must
 -- not block a capability the way the reference's @ccall unsafe@ per-block calls may).
--- Compressed blocks are INDEPENDENT, so no previous input has to be kept alive;
+-- Compressed blocks are INDEPENDENT by default, so no previous input has to be kept alive
+-- ('setLinkedCompress' makes the blocks of one batch a linked stream like the reference's:
+-- a batch is handed over as a whole, so its arrays are alive for the duration of the call);
 -- decompression keeps the previous OUTPUT array alive exactly like the reference
 -- (it is the dictionary of the next block of a linked stream).
 module Streamly.Internal.LZ4.GPU
     ( Engine
     , newEngine
     , freeEngine
+    , setLinkedCompress
     , compressChunksGPU
     , decompressChunksRawGPU
     )
@@ -61,6 +64,8 @@ foreign import ccall safe "mi355lz4.h mi355lz4_destroy"
     c_destroy :: Ptr C_Engine -> IO ()
 foreign import ccall unsafe "mi355lz4.h mi355lz4_compress_bound"
     c_bound :: CInt -> CInt
+foreign import ccall unsafe "mi355lz4.h mi355lz4_set_linked_compress"
+    c_setLinkedCompress :: Ptr C_Engine -> CInt -> IO CInt
 
 -- replaces c_compressFastContinue (Streamly/Internal/LZ4.hs:123-131), N blocks per call
 foreign import ccall safe "mi355lz4.h mi355lz4_compress_batch"
@@ -93,6 +98,14 @@ newEngine dev = alloca $ \pp -> do
 
 freeEngine :: Engine -> IO ()
 freeEngine (Engine p) = c_destroy p
+
+-- | 'True': 'compressChunksGPU' writes a linked stream (the block before is a block's
+-- dictionary, what @LZ4_compress_fast_continue@ does with the previous chunk,
+-- Streamly/Internal/LZ4.hs:376,389); 'decompressChunksRawGPU' reads either kind.
+setLinkedCompress :: Engine -> Bool -> IO ()
+setLinkedCompress (Engine p) on = do
+    rc <- c_setLinkedCompress p (if on then 1 else 0)
+    when (rc /= 0) $ error "mi355lz4_set_linked_compress failed"
 
 batchBlocks :: Int
 batchBlocks = 4096
