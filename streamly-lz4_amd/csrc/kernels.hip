@@ -702,6 +702,9 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 #ifndef PTR_RUN
 #define PTR_RUN 16
 #endif
+#ifndef PTR_ILP
+#define PTR_ILP 1                  // groups per thread advancing in lock step: more requests in flight LOSE (2: -8 %, 4: -15 %),
+#endif                             // the passes are bound by the number of scattered requests, not by their latency
 __device__ __forceinline__ void ptr_map(unsigned wg, int &blkRel, int &part)
 {
 #ifdef PTR_FLAT_MAP
@@ -749,27 +752,53 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsign
         // four pointers per thread (16-byte accesses)
         uint4 *P4 = (uint4 *)(P + bLo);
         const int q1 = x1 >> 2;
-        for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
-            uint4 v = P4[q];
-            if ((v.x & v.y & v.z & v.w) & PTR_FINAL) continue;
-            // One hop for all four per step.  Neighbouring bytes of a match have neighbouring sources, hop after hop,
-            // until a chain leaves its match: while the four pointers are consecutive they are fetched with ONE
-            // 16-byte request; otherwise with up to four requests that are in flight together.
+        // One hop for all four pointers of a group per step.  Neighbouring bytes of a match have neighbouring sources,
+        // hop after hop, until a chain leaves its match: while the four pointers are consecutive they are fetched
+        // with ONE 16-byte request; otherwise with up to four requests that are in flight together.
+        auto hop = [&](uint4 &v) -> bool {                 // false: nothing left to follow
+            const bool o0 = !(v.x & PTR_FINAL), o1 = !(v.y & PTR_FINAL), o2 = !(v.z & PTR_FINAL), o3 = !(v.w & PTR_FINAL);
+            if (!(o0 || o1 || o2 || o3)) return false;
+            if (o0 && o1 && o2 && o3 && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
+                uint4 w;
+                __builtin_memcpy(&w, P + v.x, 16);
+                v = w;
+            } else {
+                const uint32_t n0 = o0 ? P[v.x] : v.x, n1 = o1 ? P[v.y] : v.y, n2 = o2 ? P[v.z] : v.z, n3 = o3 ? P[v.w] : v.w;
+                v.x = n0; v.y = n1; v.z = n2; v.w = n3;
+            }
+            return true;
+        };
+        auto unresolved = [](const uint4 &v) { return !((v.x & v.y & v.z & v.w) & PTR_FINAL); };
+        for (int qb = (x0 >> 2) + (int)threadIdx.x; qb < q1; qb += 256 * PTR_ILP) {
+            uint4 v[PTR_ILP];
+            bool live[PTR_ILP];
+#pragma unroll
+            for (int g = 0; g < PTR_ILP; g++) {
+                const int q = qb + 256 * g;
+                live[g] = q < q1;
+                v[g] = live[g] ? P4[q] : make_uint4(PTR_FINAL, PTR_FINAL, PTR_FINAL, PTR_FINAL);
+                live[g] = live[g] && unresolved(v[g]);
+            }
+            bool dirty[PTR_ILP];
+#pragma unroll
+            for (int g = 0; g < PTR_ILP; g++) dirty[g] = live[g];
 #pragma unroll 1
-            for (int k = 0; k <= PTR_JUMPS; k++) {
-                const bool o0 = !(v.x & PTR_FINAL), o1 = !(v.y & PTR_FINAL), o2 = !(v.z & PTR_FINAL), o3 = !(v.w & PTR_FINAL);
-                if (!(o0 || o1 || o2 || o3)) break;
-                if (k == PTR_JUMPS) { open = true; break; }
-                if (o0 && o1 && o2 && o3 && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
-                    uint4 w;
-                    __builtin_memcpy(&w, P + v.x, 16);
-                    v = w;
-                } else {
-                    const uint32_t n0 = o0 ? P[v.x] : v.x, n1 = o1 ? P[v.y] : v.y, n2 = o2 ? P[v.z] : v.z, n3 = o3 ? P[v.w] : v.w;
-                    v.x = n0; v.y = n1; v.z = n2; v.w = n3;
+            for (int k = 0; k < PTR_JUMPS; k++) {
+                bool any = false;
+#pragma unroll
+                for (int g = 0; g < PTR_ILP; g++) {
+                    if (live[g]) live[g] = hop(v[g]);
+                    any = any || live[g];
+                }
+                if (!any) break;
+            }
+#pragma unroll
+            for (int g = 0; g < PTR_ILP; g++) {
+                if (dirty[g]) {
+                    P4[qb + 256 * g] = v[g];
+                    if (unresolved(v[g])) open = true;
                 }
             }
-            P4[q] = v;
         }
         for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
             const uint32_t e = P[bLo + (uint32_t)x];
