@@ -1,9 +1,11 @@
 // kernels.hip -- gfx950 kernels of the MI355X LZ4 block engine and their launchers.
 //
-//   K1  k_decode_seq / k_decode_linked   block decode (decode_seq.hpp)
-//   K2  k_encode<TabT>                   block encode (encode_wave.hpp)
-//   K3  k_scan_u64 + k_copy_ragged       size scan + compaction into the framed stream
-//       k_index                          uncompressed-size scan from block headers
+//   K1  k_decode_par / k_decode_seq      block decode (decode_par.hpp, decode_seq.hpp)
+//       k_decode_tolerant, k_ptr_*       linked streams, second pass (linked_ptr.hpp)
+//       k_decode_fixup_regions / _linked ... its in-order fallbacks (linked_replay.hpp)
+//   K2  k_encode<TabT, DICT>             block encode, independent or linked (encode_wave.hpp)
+//   K3  k_scan_u64 + k_copy_slots        size scan + compaction into the framed stream
+//       k_header_sizes                   uncompressed-size scan from block headers
 //       k_generate                       synthetic inputs (bench/test support)
 //
 // Everything is HBM/LDS byte work; there is deliberately no MFMA anywhere.
