@@ -40,6 +40,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", action="store_true", help="run on 10 MiB of the text-like generator when the corpus is absent")
     ap.add_argument("--cpu", action="store_true", help="also time the reference codec on one host core")
+    ap.add_argument("--linked", action="store_true",
+                    help="linked compression (previous block = dictionary): the pre-compressed inputs are linked streams like "
+                         "the reference's own, and so is what the compress benchmarks write")
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     import corpus
@@ -57,6 +60,7 @@ def main():
         return
     import streamly_lz4_amd as S
     eng = S.Engine(0)
+    eng.set_linked_compress(args.linked)
     if not inputs:
         import torch
         for k, n in enumerate(names):
@@ -87,7 +91,8 @@ def main():
             out = fn(chunks_of(data, bufsize))
             out_bytes = sum(len(a) for a in out)                            # drain
             best = min(best, time.perf_counter() - t0)
-        line = {"group": group, "benchmark": "bufsize(%d)/%s" % (bufsize, name), "input": label, "input_bytes": len(data),
+        line = {"group": group, "benchmark": "bufsize(%d)/%s" % (bufsize, name), "input": label,
+                "blocks": "linked" if args.linked else "independent", "input_bytes": len(data),
                 "output_bytes": out_bytes, "seconds": round(best, 6), "GBps_uncompressed": round(raw_bytes / best / 1e9, 4)}
         if cpu_fn is not None and ref is not None:
             t0 = time.perf_counter()
