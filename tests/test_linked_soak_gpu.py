@@ -1,0 +1,60 @@
+"""Soak test of the linked-stream decode (pointer pass + its fallbacks) against the oracle: many random streams with
+random corruptions, ragged block sizes and random segment sizes.  Off by default (LINKED_SOAK=<trials> turns it on):
+it is meant to be run by hand on the GPU box after a change to csrc/linked_*.hpp."""
+import os
+import random
+
+import pytest
+
+from test_parity_gpu import _decode_streams, split_blocks
+
+pytestmark = pytest.mark.gpu
+TRIALS = int(os.environ.get("LINKED_SOAK", "0"))
+
+
+@pytest.mark.skipif(TRIALS <= 0, reason="soak test: set LINKED_SOAK=<trials>")
+def test_linked_soak(engine, oracle, monkeypatch):
+    rng = random.Random(int(os.environ.get("LINKED_SOAK_SEED", "1")))
+    for trial in range(TRIALS):
+        kind = rng.choice(["text", "lzsynth", "text"])
+        bl = rng.choice([65536, 65536, 32768, 16384, 4096, 1000])
+        nblk = rng.randint(2, 24)
+        d = oracle.gen(kind, nblk, 65536, first_block=rng.randrange(1 << 20)).tobytes()[: nblk * bl]
+        shape = rng.random()
+        if shape < 0.15:
+            pat = d[: rng.randint(1, 5000)]
+            d = (pat * (len(d) // len(pat) + 1))[: len(d)]
+        elif shape < 0.25:
+            d = d[:bl] * nblk
+        elif shape < 0.3:
+            d = bytes(len(d))
+        fr = bytearray(oracle.frame_compress(d, bl, rng.choice([1, 1, 3, 50]), 8, True))
+        blocks = split_blocks(bytes(fr))
+        for _ in range(rng.choice([0, 0, 1, 1, 2, 5])):
+            bi = rng.randrange(0, len(blocks))
+            start = sum(len(b) for b in blocks[:bi]) + 8
+            pos = start + rng.randrange(max(1, len(blocks[bi]) - 8))
+            fr[pos] = rng.randrange(256) if rng.random() < 0.5 else fr[pos] ^ (1 << rng.randrange(8))
+        monkeypatch.setenv("MI355LZ4_LINKED_PTR_BLOCKS", str(rng.choice([1, 2, 3, 7, 4096])))
+        monkeypatch.setenv("MI355LZ4_LINKED_POOL_BLOCKS", str(rng.choice([2, 5, 16384, 16384])))
+        dict_bytes, eres, eouts = None, [], []
+        for b in split_blocks(bytes(fr)):
+            cap = int.from_bytes(b[4:8], "little")
+            if cap < 0 or cap > 1 << 20:
+                cap = 0
+            code, dec = oracle.decompress_block(b[8:], cap, dict_bytes)
+            eres.append(code)
+            eouts.append(dec if code >= 0 else None)
+            if code > 0:
+                dict_bytes = dec
+        mode = rng.choice(["one", "one", "streams"])
+        frs = [bytes(fr)] if mode == "one" else [bytes(fr), bytes(fr)]
+        out, res, ulen, first = _decode_streams(engine, frs, mode)
+        reps = len(frs)
+        assert res == eres * reps, (trial, res, eres)
+        o = 0
+        for r in range(reps):
+            for j, e in enumerate(eouts):
+                if e is not None:
+                    assert out[o:o + len(e)] == e, (trial, r, j)
+                o += ulen[r * len(eouts) + j]
