@@ -562,7 +562,9 @@ extern "C" int mi355lz4_decompress_streams_device(mi355lz4_ctx *c, const uint8_t
 {
     if (nStreams < 0 || (nStreams > 0 && !streamFirst))
         return fail(MI355LZ4_E_ARG, "decompress_streams_device: bad stream table");
-    if (nStreams == 0) return MI355LZ4_OK;
+    if (nStreams == 0)                        // no streams: every block is decoded on its own
+        return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, 0, out, outOff, outCap,
+                             result, nullptr, 0);
     return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, 1, out, outOff, outCap,
                          result, nullptr, 0, streamFirst, nStreams);
 }

@@ -782,6 +782,24 @@ def test_single_linked_stream_deep_chains(engine, oracle, linked_variant):
         assert res == ulen and out == d + d, name
 
 
+def test_streams_call_without_streams_decodes_every_block(engine, oracle):
+    """nStreams = 0: every block lies outside every stream and is decoded on its own."""
+    import torch
+    dev = torch.device("cuda:0")
+    d = oracle.gen("lzsynth", 5, 16384, first_block=2).tobytes()
+    fr = oracle.frame_compress(d, 16384, 1, 8, False)
+    blob, boff, first, ulen = _stream_layout([fr])
+    buf = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    off = torch.tensor(boff, dtype=torch.int64, device=dev)
+    ooff = torch.arange(6, dtype=torch.int64, device=dev) * 16384
+    out = torch.zeros(5 * 16384, dtype=torch.uint8, device=dev)
+    res = torch.zeros(5, dtype=torch.int32, device=dev)
+    sf = torch.zeros(1, dtype=torch.int32, device=dev)
+    engine.decompress_streams_device(buf, len(blob), off, 5, sf, 0, out, ooff, res)
+    engine.synchronize()
+    assert res.cpu().tolist() == [16384] * 5 and out.cpu().numpy().tobytes() == d
+
+
 def test_linked_streams_host_api(engine, oracle):
     """mi355lz4_decompress_streams (host buffers) == the device entry point == the raw data."""
     datas, frs = [], []
