@@ -67,9 +67,11 @@ public:
     // within a batch; Internal/LZ4.hs:376,389 keeps the previous chunk alive for exactly this); decompressChunks
     // reads either kind.  Default off: independent blocks.
     void setLinkedCompress(bool on);
+    bool linkedCompress() const { return linked_; }
 private:
     mi355lz4_ctx *ctx_ = nullptr;
     size_t batch_;
+    bool linked_ = false;
 };
 
 // ---- Streamly.LZ4 / Streamly.Internal.LZ4 -------------------------------------

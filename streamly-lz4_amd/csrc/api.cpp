@@ -532,6 +532,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             seg = pseg;
         }
     }
+    (void)hipGetLastError();          // scratch that could not be had is not an error: the serial walk needs none
     for (int p0 = first; p0 <= last; p0 += pool) {
         const int p1 = (last + 1 - p0 < pool) ? last + 1 : p0 + pool;
         a.segFirst = p0; a.segEnd = p1;

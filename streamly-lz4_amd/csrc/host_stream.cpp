@@ -76,7 +76,7 @@ Engine::Engine(int device, size_t batchBlocks) : batch_(batchBlocks ? batchBlock
     if (mi355lz4_create(&ctx_, device) != MI355LZ4_OK)
         throw Error(std::string("streamly_lz4::Engine: ") + mi355lz4_last_error());
 }
-void Engine::setLinkedCompress(bool on) { mi355lz4_set_linked_compress(ctx_, on ? 1 : 0); }
+void Engine::setLinkedCompress(bool on) { mi355lz4_set_linked_compress(ctx_, on ? 1 : 0); linked_ = on; }
 
 Engine::~Engine() { mi355lz4_destroy(ctx_); }
 
@@ -477,6 +477,7 @@ int slz4_engine_create(slz4_engine **out, int device, size_t batchBlocks)
 }
 void slz4_engine_destroy(slz4_engine *h) { if (h) { delete h->e; delete h; } }
 void slz4_engine_set_batch(slz4_engine *h, size_t n) { if (h) h->e->setBatchBlocks(n); }
+void slz4_engine_set_linked_compress(slz4_engine *h, int on) { if (h) h->e->setLinkedCompress(on != 0); }
 mi355lz4_ctx *slz4_engine_ctx(slz4_engine *h) { return h ? h->e->ctx() : nullptr; }
 
 size_t slz4_arrays_count(const slz4_arrays *a) { return a ? a->v.size() : 0; }

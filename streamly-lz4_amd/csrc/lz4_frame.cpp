@@ -100,10 +100,11 @@ Array lz4FrameCompress(const Array &data, int speed, Engine &eng, const Lz4Frame
         }
         Array framed(cap);
         size_t outLen = 0;
-        if (opt.linkedBlocks) eng.setLinkedCompress(true);
+        const bool was = eng.linkedCompress();
+        eng.setLinkedCompress(opt.linkedBlocks);
         const int r = mi355lz4_compress_batch(eng.ctx(), ptrs.data(), lens.data(), (int)nb, speed < 0 ? 0 : speed, 4,
                                               framed.data(), cap, &outLen, flen.data(), status.data());
-        if (opt.linkedBlocks) eng.setLinkedCompress(false);
+        eng.setLinkedCompress(was);
         if (r != MI355LZ4_OK) throw Error(std::string("lz4FrameCompress: ") + mi355lz4_last_error());
         size_t pos = 0;
         for (size_t i = 0; i < nb; i++) {

@@ -117,6 +117,7 @@ def _load():
     sig("slz4_engine_create", C.c_int, C.POINTER(vp), C.c_int, C.c_size_t)
     sig("slz4_engine_destroy", None, vp)
     sig("slz4_engine_set_batch", None, vp, C.c_size_t)
+    sig("slz4_engine_set_linked_compress", None, vp, C.c_int)
     sig("slz4_engine_ctx", vp, vp)
     sig("slz4_arrays_count", C.c_size_t, vp)
     sig("slz4_arrays_len", C.c_size_t, vp, C.c_size_t)
@@ -285,7 +286,7 @@ class Engine:
 
     def set_linked_compress(self, on):
         """Compress calls write ONE linked stream (previous block = dictionary), like the reference's compressor."""
-        _check(lib.mi355lz4_set_linked_compress(self.ctx, int(bool(on))), "set_linked_compress")
+        lib.slz4_engine_set_linked_compress(self._h, int(bool(on)))
 
     def use_stream(self, hip_stream):
         """Pin the engine to one caller-owned hipStream_t (stops following torch's current stream)."""
