@@ -55,3 +55,17 @@ cfg = S.defaultBlockConfig
 arrs = [fr[i:i + BL] for i in range(0, len(fr), BL)]
 print("  decompressChunks combinator: %.3f ms" % best(lambda: S.decompressChunks(cfg, arrs, eng)))
 print("  compressChunks combinator: %.3f ms" % best(lambda: S.compressChunks(cfg, 1, blocks, eng)))
+# the C++ mirror alone (its C surface, arrays packed beforehand, results left in the C++ vectors)
+data, lens, n = S._pack(arrs)
+h = C.c_void_p()
+def mirror_dec():
+    rc = S.lib.slz4_decompress_chunks(eng._h, cfg.blockSize, 0, data.ctypes.data_as(u8p), lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(h))
+    assert rc == 0
+    S.lib.slz4_arrays_free(h)
+print("  C++ mirror decompressChunks (no Python packing/unpacking): %.3f ms" % best(mirror_dec))
+data2, lens2, n2 = S._pack(blocks)
+def mirror_cmp():
+    rc = S.lib.slz4_compress_chunks(eng._h, cfg.blockSize, 1, data2.ctypes.data_as(u8p), lens2.ctypes.data_as(C.POINTER(C.c_uint64)), n2, C.byref(h))
+    assert rc == 0
+    S.lib.slz4_arrays_free(h)
+print("  C++ mirror compressChunks (no Python packing/unpacking): %.3f ms" % best(mirror_cmp))
