@@ -144,8 +144,8 @@ def host_api_rates(S, eng, src, BL, kind):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="decompress", choices=sorted(WORKLOADS))
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default: workload's)")
     ap.add_argument("--decoder", type=int, default=0, help="0 auto, 1 sequence-at-a-time, 2 lane-parallel")
