@@ -479,10 +479,10 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
-        // the standalone pass counts the blocks that need their dictionary: {count, first, last}
-        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 16))) return r;
+        // the standalone pass counts the blocks that need their dictionary: {count, first, last, -, largest capacity}
+        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 32))) return r;
         a.linkStat = (uint32_t *)c->linkBuf.p;
-        HIP_TRY(hipMemsetAsync(a.linkStat, 0, 16, c->stream));
+        HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
         HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
     }
     if (c->decoder == 1)
@@ -494,7 +494,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // call waits for the standalone pass (a stream of independent blocks pays this wait and nothing else).
     uint32_t *stat = (uint32_t *)c->pinStat.p;
     launch_longest_stream(a, c->stream);
-    HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (stat[0] == 0) return check_launch("decode launch");
     const int first = (int)stat[1], last = (int)stat[2];
@@ -513,19 +513,24 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     const bool walkStreams = streamFirst && !getenv("MI355LZ4_LINKED_PTR") &&
                              0.42 * (double)(stat[3] > 0 ? stat[3] - 1 : 0) * (double)(1 + nStreams / 5000) <
                                  0.55 + 1.15e-3 * (double)stat[0];
+    // The defaults are sized for 64 KiB blocks; a bigger block takes as many list regions and pointers as it has
+    // 64 KiB pieces (blocks beyond 4 MiB have no list and are walked), so fewer blocks make a segment.
     const int span = last - first + 1;
-    const int pool = (poolMax > 0 && !walkStreams) ? ((span < poolMax) ? span : poolMax) : span;
+    const int per = (int)((stat[4] + 65535u) / 65536u) > 0 ? (int)((stat[4] + 65535u) / 65536u) : 1;
+    const int poolBlocks = envPool ? poolMax : (poolMax / per > 0 ? poolMax / per : 1);
+    const int ptrBlocks = (envSeg && atoi(envSeg) > 0) ? ptrMax : (ptrMax / per > 0 ? ptrMax / per : 1);
+    const int pool = (poolMax > 0 && !walkStreams) ? ((span < poolBlocks) ? span : poolBlocks) : span;
     int seg = pool;
-    if (poolMax > 0 && !walkStreams && dev_reserve(c->tolPool, (size_t)pool * tol_region_bytes()) == 0 &&
+    if (poolMax > 0 && !walkStreams && dev_reserve(c->tolPool, (size_t)pool * per * tol_region_bytes()) == 0 &&
         dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
-        a.tolPool = c->tolPool.p; a.tolRegions = pool;
+        a.tolPool = c->tolPool.p; a.tolRegions = pool * per;
         a.tolCounter = (uint32_t *)c->tolMeta.p;
         a.tolRegion = (int32_t *)c->tolMeta.p + 4;
         a.tolCount = a.tolRegion + nBlocks;
         a.tolSize = a.tolCount + nBlocks;
-        const int pseg = (pool < ptrMax) ? pool : ptrMax;
-        const size_t ptrs = ((size_t)pseg + 1) * 65536 + 65536;
-        if (usePtr && dev_reserve(c->ptrBuf, ptrs * sizeof(uint32_t)) == 0) {
+        const int pseg = (pool < ptrBlocks) ? pool : ptrBlocks;
+        const size_t ptrs = ((size_t)pseg + 1) * per * 65536 + 65536;
+        if (usePtr && ptrs < ((size_t)1 << 31) && dev_reserve(c->ptrBuf, ptrs * sizeof(uint32_t)) == 0) {
             a.ptr = (uint32_t *)c->ptrBuf.p; a.ptrCap = ptrs;
             a.ptrCtl = (uint8_t *)c->linkBuf.p + 64;
             a.ptrBad = (uint32_t *)((uint8_t *)c->linkBuf.p + 64 + ptr_ctl_bytes());

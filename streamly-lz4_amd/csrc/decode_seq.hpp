@@ -65,19 +65,27 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dstGeneric, int op, int
 // destination.  Everything else is copied as usual.  A later pass walks the stream in order and replays each
 // block's list with the previous block's final output beside it (kernels.hip: k_decode_fixup_regions).
 // ---------------------------------------------------------------------------
-struct TolEntry { uint16_t dpos, ml; int32_t src; };            // 8 bytes; src < 0: starts in the previous block's output
+// One deferred match in 8 bytes: destination (22 bits), length (22 bits), offset (16 bits; the source is
+// destination - offset and is negative when the match starts in the previous block's output).  Blocks of up to
+// TOL_MAX_BLOCK bytes can be listed; a bigger one goes to the serial path.
+#define TOL_MAX_BLOCK (1 << 22)
+typedef uint64_t TolEntry;
 __device__ __forceinline__ TolEntry tol_entry(int dpos, int src, uint32_t ml)
 {
-    TolEntry e;
-    e.dpos = (uint16_t)dpos; e.ml = (uint16_t)min(ml, 65535u); e.src = src;
-    return e;
+    return (uint64_t)(uint32_t)dpos | ((uint64_t)ml << 22) | ((uint64_t)(uint32_t)(dpos - src) << 44);
+}
+__device__ __forceinline__ void tol_unpack(TolEntry e, int &dpos, int &ml, int &spos)
+{
+    dpos = (int)(uint32_t)(e & 0x3fffffu);
+    ml = (int)(uint32_t)((e >> 22) & 0x3fffffu);
+    spos = dpos - (int)(uint32_t)((e >> 44) & 0xffffu);
 }
 
 struct TolCtx {
     uint32_t taint[128];        // 4096 granules
     TolEntry *list;             // global memory, cap entries
     uint32_t cap, count;        // count may run past cap (overflow: the block falls back to the serial path)
-    uint32_t granShift;         // log2(granule bytes), >= 4
+    uint32_t granShift;         // log2(granule bytes), >= 4: 16-byte granules for blocks of up to 64 KiB
 };
 
 // any tainted granule in output bytes [lo, hi) ?  (lo < hi; per-lane values)
@@ -115,7 +123,7 @@ __device__ __forceinline__ bool tol_defer_uniform(TolCtx *t, int op, int match, 
     if (!defer || ml == 0) return false;
     if (lane_id() == 0) {
         if (t->count < t->cap) t->list[t->count] = tol_entry(op, match, ml);
-        t->count += (ml > 65535u) ? t->cap + 1u : 1u;          // a match that long does not fit an entry: no list
+        t->count += 1u;
         tol_taint(t, op, op + (int)ml);
     }
     wave_fence();

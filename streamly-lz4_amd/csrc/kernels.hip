@@ -51,12 +51,13 @@ __device__ __forceinline__ int read_block_header(const DecodeArgs &a, int blk, c
 // A codec error (not a header rejection) is what a block of a linked stream reports when it is decoded without
 // its dictionary: the second pass is launched only when the standalone pass counted some.
 __device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7F000000; }
-__device__ __forceinline__ void note_link_failure(const DecodeArgs &a, int blk, int r)
+__device__ __forceinline__ void note_link_failure(const DecodeArgs &a, int blk, int r, int cap)
 {
     if (a.linkStat && is_codec_error(r)) {
         atomicAdd(&a.linkStat[0], 1u);
         atomicMin(&a.linkStat[1], (uint32_t)blk);
         atomicMax(&a.linkStat[2], (uint32_t)blk);
+        atomicMax(&a.linkStat[4], (uint32_t)cap);          // the largest such block sizes the second pass's scratch
     }
 }
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
     if (r == 0)
         r = decode_block_seq(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                              a.framed + a.framedLen);
-    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r); }
+    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r, cap); }
 }
 
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
@@ -321,7 +322,7 @@ __global__ PAR_OCC void k_decode_par(DecodeArgs a, unsigned long long *stats)
     if (r == 0)
         r = decode_block_par<STATS, false>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                                     a.framed + a.framedLen, lds, stats);
-    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r); }
+    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r, cap); }
 }
 
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s)
@@ -399,18 +400,22 @@ __global__ __launch_bounds__(64, 3) void k_decode_tolerant(DecodeArgs a)
     const uint8_t *data = nullptr;
     int compLen = 0, cap = 0;
     int region = -1, count = 0, size = -1;
-    if (read_block_header(a, blk, data, compLen, cap) == 0 && cap <= RPL_HALF) {
+    if (read_block_header(a, blk, data, compLen, cap) == 0 && cap <= TOL_MAX_BLOCK) {
+        // one list region (TOL_LIST_CAP entries) per 64 KiB of capacity, taken in one piece
+        const unsigned need = (unsigned)max(1, (cap + RPL_HALF - 1) / RPL_HALF);
         unsigned got = 0;
-        if (lane_id() == 0) got = atomicAdd(a.tolCounter, 1u);
+        if (lane_id() == 0) got = atomicAdd(a.tolCounter, need);
         got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-        if (got < (unsigned)a.tolRegions) {
+        if (got + need <= (unsigned)a.tolRegions) {
             region = (int)got;
             for (int i = lane_id(); i < 128; i += LZ4_WAVE) lds.t.taint[i] = 0;
             if (lane_id() == 0) {
                 lds.t.list = (TolEntry *)a.tolPool + (size_t)region * TOL_LIST_CAP;
-                lds.t.cap = TOL_LIST_CAP;
+                lds.t.cap = need * TOL_LIST_CAP;
                 lds.t.count = 0;
-                lds.t.granShift = 4;
+                uint32_t gs = 4;                                   // 4096 granules cover the block
+                while (((uint32_t)cap >> gs) > 4096u) gs++;
+                lds.t.granShift = gs;
             }
             wave_fence();
             size = decode_block_par<false, false, true>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
@@ -418,6 +423,7 @@ __global__ __launch_bounds__(64, 3) void k_decode_tolerant(DecodeArgs a)
             size = uni(size);
             wave_fence();
             count = (int)lds.t.count;
+            if ((unsigned)count > need * TOL_LIST_CAP) region = -1;        // the list overflowed: no list
         }
     }
     if (lane_id() == 0) { a.tolRegion[blk] = region; a.tolCount[blk] = count; a.tolSize[blk] = size; }
@@ -576,8 +582,7 @@ __device__ __forceinline__ int ptr_stream(const DecodeArgs &a, int blk, bool &ha
 // a block the tolerant pass left a usable list for (stable while the second pass runs: result[] is not)
 __device__ __forceinline__ bool ptr_listed(const DecodeArgs &a, int blk)
 {
-    return blk >= a.segFirst && blk < a.segEnd && a.tolRegion[blk] >= 0 && a.tolSize[blk] > 0 &&
-           a.tolCount[blk] <= TOL_LIST_CAP;
+    return blk >= a.segFirst && blk < a.segEnd && a.tolRegion[blk] >= 0 && a.tolSize[blk] > 0;
 }
 // decoded size of block blk as far as the second pass knows it, 0 = no output
 __device__ __forceinline__ int ptr_size(const DecodeArgs &a, int blk)
@@ -649,9 +654,7 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
     const int n = a.tolCount[blk];
     const int lane = tid & 63;
     bool bad = false;
-    auto unpack = [](uint64_t w, int &dpos, int &ml, int &spos) {
-        dpos = (int)(uint32_t)(w & 0xffffu); ml = (int)(uint32_t)((w >> 16) & 0xffffu); spos = (int)(uint32_t)(w >> 32);
-    };
+    auto unpack = [](uint64_t w, int &dpos, int &ml, int &spos) { tol_unpack(w, dpos, ml, spos); };
     // The list is in stream order: destinations ascend and do not overlap.  Entry e writes the pointers of ITS range
     // of the block in one go: the clean bytes between the entry before it and itself (roots), then its own bytes.
     for (int e0 = 0; e0 < n; e0 += 256) {

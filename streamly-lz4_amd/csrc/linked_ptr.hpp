@@ -17,7 +17,7 @@
 // already names a root.
 //
 // Anything the reference would not have accepted (an offset beyond the dictionary, :1764; a dictionary match
-// that ends inside the last literals, :1884-1889), and any block without a usable list, turns its STREAM down: its blocks
+// that ends inside the last literals, :1884-1889), and any block without a usable list (overflow, > 4 MiB), turns its STREAM down: its blocks
 // are left untouched and walked by linked_replay.hpp / the exact decoder, which also yields the
 // reference's error codes.  (DecodeArgs::ptrBad: one flag per stream.)
 #pragma once

@@ -18,7 +18,7 @@
 namespace lz4dev {
 
 #define RPL_HALF 65536
-#define TOL_LIST_CAP 8192          // deferred entries per block (64 KiB of 8-byte entries); a block with more falls back
+#define TOL_LIST_CAP 8192          // deferred entries per 64 KiB of block capacity (64 KiB of 8-byte entries); a block with more falls back
                                    // to the serial path.  Text-like data defers nearly every match (most bytes of a block
                                    // originate in its predecessor), ~6 500 per 64 KiB block.
 
@@ -93,7 +93,8 @@ __device__ bool replay_block(ReplayLds &L, RplCtl &C, const TolEntry *list, int 
         const int cnt = min(n - base, RPL_THREADS);
         const bool has = tid < cnt;
         const uint64_t nxt = fetch(base + RPL_THREADS);
-        const int dpos = (int)(uint32_t)(cur & 0xffffu), ml = (int)(uint32_t)((cur >> 16) & 0xffffu), spos = (int)(uint32_t)(cur >> 32);
+        int dpos, ml, spos;
+        tol_unpack(cur, dpos, ml, spos);
         cur = nxt;
         bool good = !has || (ml > 0 && spos < dpos && dpos + ml <= size && spos >= -dictLen);
         // a match that starts in the dictionary must end LASTLITERALS before the end of the output (:1884-1889)

@@ -99,17 +99,18 @@ def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
     assert best[True] <= best[False] * 1.02 + 0.02, rec
 
 
-@pytest.mark.parametrize("kind,n_blocks,repeat", [("text", 1024, 1), ("lzsynth_shared", 512, 1), ("text", 1024, 10)])
-def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks, repeat):
+@pytest.mark.parametrize("kind,n_blocks,repeat,bl", [("text", 1024, 1, 65536), ("lzsynth_shared", 512, 1, 65536),
+                                                     ("text", 1024, 10, 65536), ("text", 256, 4, 262144),
+                                                     ("text", 64, 4, 1 << 20)])
+def test_single_linked_stream_rate(engine, slz4, oracle, kind, n_blocks, repeat, bl):
     """ONE long stream written by the reference's linked compressor (what a reference-written file is): the
     tolerant parallel pass + the data-parallel pointer pass (linked_ptr.hpp).  Bit-exact; the rate is recorded.
     repeat > 1: the framed stream is appended to itself (still one valid linked stream: a block written without
     a dictionary may follow any block), long enough to span several segments of the second pass."""
     import torch
     dev = torch.device("cuda:0")
-    bl = 65536
     if kind == "text":
-        data = oracle.gen("text", n_blocks, bl, first_block=7).tobytes()
+        data = oracle.gen("text", n_blocks * (bl // 65536), 65536, first_block=7).tobytes()
     else:
         # every block built from the same vocabulary as its predecessor: long matches across the block seam
         base = oracle.gen("lzsynth", 2, bl, first_block=3).tobytes()

@@ -761,6 +761,38 @@ def test_single_linked_stream_fuzz_codes(engine, oracle, linked_variant):
             o += ulen[j]
 
 
+@pytest.mark.parametrize("bl", [262144, 1 << 20, 4 << 20, (4 << 20) + 65536])
+def test_single_linked_stream_large_blocks(engine, oracle, linked_variant, bl):
+    """Linked streams with blocks above 64 KiB (BlockMax256KB .. BlockMax4MB, or big arrays under BlockHasSize): a
+    block of up to 4 MiB takes as many list regions and pointers as it has 64 KiB pieces; beyond that it is walked.
+    Clean and corrupted, against the oracle's linked decode."""
+    rng = random.Random(bl)
+    nblk = 5 if bl <= (1 << 20) else 3
+    raw = oracle.gen("text", (nblk * bl + 65535) // 65536, 65536, first_block=21).tobytes()[: nblk * bl]
+    for trial in range(3):
+        fr = bytearray(oracle.frame_compress(raw, bl, 1, 8, True))
+        blocks = split_blocks(bytes(fr))
+        if trial:
+            bi = rng.randrange(1, len(blocks))
+            start = sum(len(b) for b in blocks[:bi]) + 8
+            pos = start + rng.randrange(len(blocks[bi]) - 8)
+            fr[pos] ^= 1 << rng.randrange(8)
+        dict_bytes, eres, eouts = None, [], []
+        for b in split_blocks(bytes(fr)):
+            code, dec = oracle.decompress_block(b[8:], int.from_bytes(b[4:8], "little"), dict_bytes)
+            eres.append(code)
+            eouts.append(dec if code >= 0 else None)
+            if code > 0:
+                dict_bytes = dec
+        out, res, ulen, _ = _decode_streams(engine, [bytes(fr)], "one")
+        assert res == eres, (bl, trial, res, eres)
+        o = 0
+        for j, e in enumerate(eouts):
+            if e is not None:
+                assert out[o:o + len(e)] == e, (bl, trial, j)
+            o += ulen[j]
+
+
 def test_single_linked_stream_deep_chains(engine, oracle, linked_variant):
     """Streams in which a byte's origin lies arbitrarily far back: runs (every byte copies the one before it, across
     every block seam: a chain as deep as the stream is long), short and long periods, a period longer than a block.
