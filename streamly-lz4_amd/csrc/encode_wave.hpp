@@ -7,8 +7,8 @@
 // probes 64 positions at once:
 //   * lane i hashes the 5 bytes at p + i*step with the reference's hash
 //     (cbits/lz4.c:706-716, hashLog 12) and looks its candidate up in a
-//     4096-entry table held in LDS (u16 positions for blocks <= 64 KiB,
-//     u32 above; cbits/lz4.h:578-580 is the table being replaced);
+//     4096-entry table held in LDS (16-bit entries: positions for blocks <= 64 KiB,
+//     positions modulo 64 Ki above; cbits/lz4.h:578-580 is the table being replaced);
 //   * a ballot picks the first lane whose candidate verifies (4 equal bytes
 //     within 65535, cbits/lz4.c:1003-1012); lanes up to and including it
 //     publish their positions to the table -- later lanes do not, so the
@@ -89,9 +89,11 @@ __device__ __forceinline__ int enc_scan_incl(int x)
 #define ENC_LAP(i) do { } while (0)
 #endif
 
-// A table entry as a candidate position for `myPos`.  u32 tables hold positions; u16 tables hold their low 16
-// bits, and with a dictionary in front of the block (DICT: positions run to 128 Ki) the candidate is the
-// nearest earlier position with those bits -- at most 65535 back by construction, like the reference's window.
+// A table entry as a candidate position for `myPos`.  The table holds the low 16 bits of a position.  When
+// positions stay below 64 Ki that IS the position; otherwise (DICT: a block above 64 KiB, or a dictionary in
+// front of the block) the candidate is the nearest earlier position with those bits -- at most 65535 back by
+// construction, like the reference's window; an entry older than the window names some other position inside
+// it, which the 4-byte compare then rejects like any stale candidate.
 template <typename TabT, bool DICT>
 __device__ __forceinline__ bool tab_candidate(TabT e, int myPos, uint32_t &cand)
 {

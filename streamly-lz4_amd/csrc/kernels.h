@@ -72,7 +72,7 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s);
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();
-void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s);
+void launch_encode(const EncodeArgs &a, bool bigBlocks, hipStream_t s);   // bigBlocks: some block is above 64 KiB
 void launch_compact(const uint8_t *slots, size_t slotStride, const int32_t *framedLen, int nBlocks,
                     uint8_t *dense, size_t denseCap, uint64_t *denseOff, hipStream_t s);
 void launch_interleave(const uint8_t *local, const uint64_t *localOff, int nLocal, int rank, int nRanks,

@@ -85,24 +85,27 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // K2: encode
 // ---------------------------------------------------------------------------
-template <typename TabT, bool DICT>
+// MOD: table entries are positions modulo 64 Ki (encode_wave.hpp, tab_candidate): needed when positions run beyond
+// 64 Ki -- blocks above 64 KiB, or a dictionary in front of the block (linked compression).  The table is 8 KiB
+// either way, so every block size runs at 20 waves per CU (a table of 32-bit positions would halve that).
+template <bool MOD>
 __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
 {
-    __shared__ TabT table[4096];
+    __shared__ uint16_t table[4096];
     const int blk = (int)blockIdx.x;
     const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
     const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
     uint8_t *slot = a.slots + (size_t)blk * a.slotStride;
     int dictLen = 0;
-    if (DICT && (blk > 0 || a.lookBack > 0)) {
+    if (MOD && a.linked && (blk > 0 || a.lookBack > 0)) {
         // linked stream: the block before is the dictionary when it lies directly in front of this one
         const uint64_t poff = a.srcOff ? a.srcOff[blk - 1] : (uint64_t)(blk - 1) * a.blockStride;
         const int pn = a.srcLen ? a.srcLen[blk - 1] : a.uniformLen;
         if (pn > 0 && poff + (uint64_t)pn == off) dictLen = min(pn, 65536);
     }
     int c = 0;
-    if (n >= 0 && (sizeof(TabT) == 4 || n <= 65536))
-        c = encode_block_wave<TabT, DICT>(a.src + off, n, slot + a.headerKind, a.accel, table, a.stats, dictLen);
+    if (n >= 0 && (MOD || n <= 65536))
+        c = encode_block_wave<uint16_t, MOD>(a.src + off, n, slot + a.headerKind, a.accel, table, a.stats, dictLen);
     if (lane_id() == 0) {
         store_le32(slot, c);                                   // Internal/LZ4.hs:262
         if (a.headerKind == 8) store_le32(slot + 4, n);        // Internal/LZ4.hs:261
@@ -110,17 +113,12 @@ __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
     }
 }
 
-void launch_encode(const EncodeArgs &a, bool wideTable, hipStream_t s)
+void launch_encode(const EncodeArgs &a, bool bigBlocks, hipStream_t s)
 {
     if (a.nBlocks <= 0) return;
     const dim3 grid((unsigned)a.nBlocks), wg(64);
-    if (a.linked) {
-        if (wideTable) hipLaunchKernelGGL((k_encode<uint32_t, true>), grid, wg, 0, s, a);
-        else hipLaunchKernelGGL((k_encode<uint16_t, true>), grid, wg, 0, s, a);
-    } else {
-        if (wideTable) hipLaunchKernelGGL((k_encode<uint32_t, false>), grid, wg, 0, s, a);
-        else hipLaunchKernelGGL((k_encode<uint16_t, false>), grid, wg, 0, s, a);
-    }
+    if (a.linked || bigBlocks) hipLaunchKernelGGL(k_encode<true>, grid, wg, 0, s, a);
+    else hipLaunchKernelGGL(k_encode<false>, grid, wg, 0, s, a);
 }
 
 // ---------------------------------------------------------------------------
