@@ -63,7 +63,7 @@ def test_linked_stream_rate(engine, slz4, oracle, n_streams, blocks_per_stream):
 def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
     """linked = 1 on a stream in which every block decodes standalone (what this engine's compressor writes,
     and what the C++ mirror / LZ4_decompress_safe_continue always pass) must cost nothing measurable: the
-    fixup only walks REGIONS of failed blocks (cbits/lz4.c:2347-2355 semantics are unchanged)."""
+    call only waits for the first pass to learn that no block needs a second one."""
     import torch
     dev = torch.device("cuda:0")
     bl, nb = 65536, 16384
@@ -96,7 +96,8 @@ def test_linked_flag_is_free_on_independent_blocks(engine, slz4):
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
-    assert best[True] <= best[False] * 1.02 + 0.02, rec
+    # one stream synchronisation (tens of microseconds), never a walk over the blocks (tens of milliseconds)
+    assert best[True] <= best[False] * 1.05 + 0.05, rec
 
 
 @pytest.mark.parametrize("kind,n_blocks,repeat,bl", [("text", 1024, 1, 65536), ("lzsynth_shared", 512, 1, 65536),
