@@ -318,14 +318,6 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool act = lane < nseq;
             const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
             const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
-            // prefetch the next window while this batch is copied (measured: issuing it here, before the
-            // far pass, beats issuing it after, although the far pass then also waits for it)
-            {
-                const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
-                wbase = nb;
-                wnext = fetch_window(nb);
-            }
-
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
             const bool ext = TOL && spos < 0;                       // source starts in the previous block: deferred
             const bool nearSrc = spos >= ringBase && !ext;
@@ -337,6 +329,50 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
             const bool g4 = ml < 8 && off16 >= ml;                  // 4 <= ml < 8, no self-overlap: two 4-byte chunks
             const bool fastc = g16 || g8 || g4;
+
+            // ---------------- far matches, first half: the loads.  Sources already in global memory (older than
+            // this batch: under TOL their taint is final) are requested FIRST, then the next window: vector memory
+            // returns in order, so the far data is not held up behind the window's trip to HBM, and both are in
+            // flight while the masks and the literals are done.  (Requesting the window first made every batch with
+            // a far match wait for HBM right here.)
+            const uint64_t farm = __ballot(act && !nearSrc);
+            if (TOL && farm) {
+                if (act && !nearSrc && (ext || tol_tainted(tol, spos, spos + (int)ml))) {
+                    deferred = true;
+                    tol_taint(tol, dpos, dpos + (int)ml);
+                }
+                wave_fence();
+            }
+            const uint8_t *gsrc = (DICT && spos < 0) ? dictEnd + spos : dst + spos;
+            const bool farMine = act && !nearSrc && !deferred;
+            // chunks of 16, 8 or 4 bytes; the last chunk is re-anchored at the end so that nothing past the match is
+            // written.  Far sources never overlap their destination.
+            const uint32_t fstep = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
+            const uint32_t flast = ml - fstep;
+            // Each chunk class loads into registers of its own: classes that shared destination registers made
+            // the compiler wait for one class's loads before it issued the next one's (three round trips, not one).
+            par_v4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};
+            uint64_t fa = 0, fb = 0;
+            if (farm) {
+                if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
+                if (farMine && fstep == 16) {
+                    __builtin_memcpy(&f0, gsrc, 16);
+                    __builtin_memcpy(&f1, gsrc + min(16u, flast), 16);
+                }
+                if (farMine && fstep == 8) {
+                    fa = *(const par_u64u *)(gsrc);
+                    fb = *(const par_u64u *)(gsrc + flast);
+                }
+                if (farMine && fstep == 4) {
+                    fa = (uint64_t)*(const par_u32u *)(gsrc) | ((uint64_t)*(const par_u32u *)(gsrc + flast) << 32);
+                }
+            }
+            // prefetch the next window while this batch is copied
+            {
+                const uintptr_t nb = (uintptr_t)(src + ipNext) & ~(uintptr_t)15;
+                wbase = nb;
+                wnext = fetch_window(nb);
+            }
 
             // ---------------- dependency masks (independent of the copies below: issued first so that
             // their cross-lane traffic overlaps the literal and far copies) ----------------
@@ -385,55 +421,33 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             }
             wave_fence();
 
-            // ---------------- 6. far matches: source already in global memory ----------------
-            const uint64_t farm = __ballot(act && !nearSrc);
-            if (TOL && farm) {
-                // far sources are older than this batch: their taint is final
-                if (act && !nearSrc && (ext || tol_tainted(tol, spos, spos + (int)ml))) {
-                    deferred = true;
-                    tol_taint(tol, dpos, dpos + (int)ml);
-                }
-                wave_fence();
-            }
+            // ---------------- 6. far matches, second half: into the ring (behind the literals: a literal store
+            // may run over into its own sequence's match area) ----------------
             if (farm) {
-                if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
-                const uint8_t *gsrc = (DICT && spos < 0) ? dictEnd + spos : dst + spos;
-                const bool mine = act && !nearSrc && !deferred;
-                // chunks of 8 (or 4) bytes; the last chunk is re-anchored at the end so that nothing
-                // past the match is written.  Far sources never overlap their destination.
-                const uint32_t step = (ml >= 16) ? 16u : ((ml >= 8) ? 8u : 4u);
-                const uint32_t last = ml - step;
-                for (uint32_t base = 0; __ballot(mine && base < ml); base += 32) {
-                    // every load of the pass is issued before the first store waits for one: a single
-                    // round trip to L2/HBM per 32 bytes, whatever mix of chunk sizes the lanes have
+                if (farMine && fstep == 16) {
+                    *(par_v4u *)&L.ring[mdA] = f0;
+                    *(par_v4u *)&L.ring[mdA + min(16u, flast)] = f1;
+                }
+                if (farMine && fstep == 8) {
+                    *(par_u64u *)&L.ring[mdA] = fa;
+                    *(par_u64u *)&L.ring[mdA + flast] = fb;
+                }
+                if (farMine && fstep == 4) {
+                    *(par_u32u *)&L.ring[mdA] = (uint32_t)fa;
+                    *(par_u32u *)&L.ring[mdA + flast] = (uint32_t)(fa >> 32);
+                }
+                // matches longer than 32 bytes: 32 more per step, every load of a step issued before its first store
+                for (uint32_t base = 32; __ballot(farMine && base < ml); base += 32) {
                     par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-                    const bool on = mine && base < ml;
-                    const uint32_t o0 = (step == 16) ? min(base, last) : 0u;
-                    const uint32_t o1 = (step == 16) ? min(base + 16u, last) : last;
+                    const bool on = farMine && base < ml;
+                    const uint32_t o0 = min(base, flast), o1 = min(base + 16u, flast);
                     if (on) {
-                        if (step == 16) {
-                            __builtin_memcpy(&v0, gsrc + o0, 16);
-                            __builtin_memcpy(&v1, gsrc + o1, 16);
-                        } else if (step == 8) {
-                            const uint64_t a = *(const par_u64u *)(gsrc), b = *(const par_u64u *)(gsrc + last);
-                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
-                            v1.x = (uint32_t)b; v1.y = (uint32_t)(b >> 32);
-                        } else {
-                            v0.x = *(const par_u32u *)(gsrc);
-                            v1.x = *(const par_u32u *)(gsrc + last);
-                        }
+                        __builtin_memcpy(&v0, gsrc + o0, 16);
+                        __builtin_memcpy(&v1, gsrc + o1, 16);
                     }
                     if (on) {
-                        if (step == 16) {
-                            *(par_v4u *)&L.ring[mdA + o0] = v0;
-                            *(par_v4u *)&L.ring[mdA + o1] = v1;
-                        } else if (step == 8) {
-                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
-                            *(par_u64u *)&L.ring[mdA + last] = ((uint64_t)v1.y << 32) | v1.x;
-                        } else {
-                            *(par_u32u *)&L.ring[mdA] = v0.x;
-                            *(par_u32u *)&L.ring[mdA + last] = v1.x;
-                        }
+                        *(par_v4u *)&L.ring[mdA + o0] = v0;
+                        *(par_v4u *)&L.ring[mdA + o1] = v1;
                     }
                 }
             }
@@ -468,31 +482,32 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     const uint32_t lastc = ml - cs;
                     const uint32_t o0 = g16 ? min(base, lastc) : 0u;
                     const uint32_t o1 = g16 ? min(base + 16u, lastc) : lastc;
+                    // (registers of its own for every class: shared ones make the second class's reads wait for
+                    // the first class's data, one LDS round trip per class instead of one per step)
                     par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-                    if (on) {
-                        if (g16) {
-                            v0 = *(const par_v4u *)&L.ring[msA + o0];
-                            v1 = *(const par_v4u *)&L.ring[msA + o1];
-                        } else if (g8) {
-                            const uint64_t a = *(const par_u64u *)&L.ring[msA], c = *(const par_u64u *)&L.ring[msA + o1];
-                            v0.x = (uint32_t)a; v0.y = (uint32_t)(a >> 32);
-                            v1.x = (uint32_t)c; v1.y = (uint32_t)(c >> 32);
-                        } else {
-                            v0.x = *(const par_u32u *)&L.ring[msA];
-                            v1.x = *(const par_u32u *)&L.ring[msA + o1];
-                        }
+                    uint64_t na = 0, nc = 0;
+                    if (on && g16) {
+                        v0 = *(const par_v4u *)&L.ring[msA + o0];
+                        v1 = *(const par_v4u *)&L.ring[msA + o1];
                     }
-                    if (on) {
-                        if (g16) {
-                            *(par_v4u *)&L.ring[mdA + o0] = v0;
-                            *(par_v4u *)&L.ring[mdA + o1] = v1;
-                        } else if (g8) {
-                            *(par_u64u *)&L.ring[mdA] = ((uint64_t)v0.y << 32) | v0.x;
-                            *(par_u64u *)&L.ring[mdA + o1] = ((uint64_t)v1.y << 32) | v1.x;
-                        } else {
-                            *(par_u32u *)&L.ring[mdA] = v0.x;
-                            *(par_u32u *)&L.ring[mdA + o1] = v1.x;
-                        }
+                    if (on && g8) {
+                        na = *(const par_u64u *)&L.ring[msA];
+                        nc = *(const par_u64u *)&L.ring[msA + o1];
+                    }
+                    if (on && g4) {
+                        na = (uint64_t)*(const par_u32u *)&L.ring[msA] | ((uint64_t)*(const par_u32u *)&L.ring[msA + o1] << 32);
+                    }
+                    if (on && g16) {
+                        *(par_v4u *)&L.ring[mdA + o0] = v0;
+                        *(par_v4u *)&L.ring[mdA + o1] = v1;
+                    }
+                    if (on && g8) {
+                        *(par_u64u *)&L.ring[mdA] = na;
+                        *(par_u64u *)&L.ring[mdA + o1] = nc;
+                    }
+                    if (on && g4) {
+                        *(par_u32u *)&L.ring[mdA] = (uint32_t)na;
+                        *(par_u32u *)&L.ring[mdA + o1] = (uint32_t)(na >> 32);
                     }
                     wave_fence();
                 }
