@@ -353,6 +353,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // the compiler wait for one class's loads before it issued the next one's (three round trips, not one).
             par_v4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};
             uint64_t fa = 0, fb = 0;
+            uint32_t fw0 = 0, fw1 = 0;
             if (farm) {
                 if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
                 if (farMine && fstep == 16) {
@@ -364,7 +365,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     fb = *(const par_u64u *)(gsrc + flast);
                 }
                 if (farMine && fstep == 4) {
-                    fa = (uint64_t)*(const par_u32u *)(gsrc) | ((uint64_t)*(const par_u32u *)(gsrc + flast) << 32);
+                    fw0 = *(const par_u32u *)(gsrc);
+                    fw1 = *(const par_u32u *)(gsrc + flast);
                 }
             }
             // prefetch the next window while this batch is copied
@@ -433,8 +435,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     *(par_u64u *)&L.ring[mdA + flast] = fb;
                 }
                 if (farMine && fstep == 4) {
-                    *(par_u32u *)&L.ring[mdA] = (uint32_t)fa;
-                    *(par_u32u *)&L.ring[mdA + flast] = (uint32_t)(fa >> 32);
+                    *(par_u32u *)&L.ring[mdA] = fw0;
+                    *(par_u32u *)&L.ring[mdA + flast] = fw1;
                 }
                 // matches longer than 32 bytes: 32 more per step, every load of a step issued before its first store
                 for (uint32_t base = 32; __ballot(farMine && base < ml); base += 32) {
@@ -494,8 +496,10 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                         na = *(const par_u64u *)&L.ring[msA];
                         nc = *(const par_u64u *)&L.ring[msA + o1];
                     }
+                    uint32_t nw0 = 0, nw1 = 0;
                     if (on && g4) {
-                        na = (uint64_t)*(const par_u32u *)&L.ring[msA] | ((uint64_t)*(const par_u32u *)&L.ring[msA + o1] << 32);
+                        nw0 = *(const par_u32u *)&L.ring[msA];
+                        nw1 = *(const par_u32u *)&L.ring[msA + o1];
                     }
                     if (on && g16) {
                         *(par_v4u *)&L.ring[mdA + o0] = v0;
@@ -506,8 +510,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                         *(par_u64u *)&L.ring[mdA + o1] = nc;
                     }
                     if (on && g4) {
-                        *(par_u32u *)&L.ring[mdA] = (uint32_t)na;
-                        *(par_u32u *)&L.ring[mdA + o1] = (uint32_t)(na >> 32);
+                        *(par_u32u *)&L.ring[mdA] = nw0;
+                        *(par_u32u *)&L.ring[mdA + o1] = nw1;
                     }
                     wave_fence();
                 }
