@@ -323,7 +323,6 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool nearSrc = spos >= ringBase && !ext;
             bool deferred = false;                                  // TOL: this lane's match is recorded, not copied
             const bool w8 = ml >= 8 && off16 >= 8;                  // 8-byte steps are safe
-            const bool w4 = !w8 && off16 >= 4;                      // 4-byte steps are safe (ml >= 4 always)
             const bool grp = w8 && (off16 >= 32 || off16 >= ml);    // 32-byte groups never read their own writes
             const bool g16 = grp && ml >= 16;                       // ... as two 16-byte chunks
             const bool g8 = grp && ml < 16;                         // ... as two 8-byte chunks (8 <= ml < 16)
@@ -515,22 +514,24 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     }
                     wave_fence();
                 }
-                // short offsets (rare): steps of 8 / 4 / 1 bytes one after the other, because a step may
-                // read the previous step's bytes; last chunk re-anchored at the end (idempotent rewrite)
-                if (__ballot(mine && !fastc)) {
-                    const uint32_t step = w8 ? 8u : (w4 ? 4u : 1u);
-                    const uint32_t last = ml - step;
-                    const bool slow = mine && !fastc;
-                    for (uint32_t o = 0; __ballot(slow && o < ml); o += step) {
-                        if (STATS) sc[PS_MATCH_ITERS]++;
-                        if (slow && o < ml) {
-                            const uint32_t oo = min(o, last);
-                            if (w8) *(par_u64u *)&L.ring[mdA + oo] = *(const par_u64u *)&L.ring[msA + oo];
-                            else if (w4) *(par_u32u *)&L.ring[mdA + oo] = *(const par_u32u *)&L.ring[msA + oo];
-                            else L.ring[mdA + oo] = L.ring[msA + oo];
-                        }
-                        wave_fence();
+                // self-overlapping matches (offset < length; rare): the output is the `offset` bytes in front of the
+                // destination repeated, so the whole wave writes it at once -- byte j is source byte j mod offset --
+                // one match after the other (one LDS round trip each instead of length / step of them)
+                for (uint64_t sm = __ballot(mine && !fastc); sm; sm &= sm - 1) {
+                    if (STATS) sc[PS_MATCH_ITERS]++;
+                    const int k = (int)__builtin_ctzll(sm);
+                    const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)mdA, k);
+                    const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)msA, k);
+                    const uint32_t koff = (uint32_t)__builtin_amdgcn_readlane((int)off16, k);
+                    const uint32_t kml = (uint32_t)__builtin_amdgcn_readlane((int)ml, k);
+                    const float rcp = 1.0f / (float)koff;              // j < 512, koff < 32: the quotient is off by at most one
+                    for (uint32_t j = (uint32_t)lane; j < kml; j += LZ4_WAVE) {
+                        const uint32_t q = (uint32_t)((float)j * rcp);
+                        int rem = (int)j - (int)(q * koff);
+                        if (rem < 0) rem += (int)koff; else if (rem >= (int)koff) rem -= (int)koff;
+                        L.ring[kd + j] = L.ring[ks + (uint32_t)rem];
                     }
+                    wave_fence();
                 }
                 pending = pending && !ready;
                 done |= __ballot(ready);
