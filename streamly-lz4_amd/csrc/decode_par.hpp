@@ -401,12 +401,22 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const uint32_t sA = litStart;
                 const uint32_t dA = (uint32_t)(outStart - ringBase) + A;
                 const uint32_t n = act ? lit : 0u;
-                if (n > 8) {                                    // rare (token nibble 15 or close to it)
-                    const uint32_t last = n - 8;
-                    for (uint32_t o = 0;; o += 8) {
+                if (n > 16) {                                   // rare (token nibble 15 with an extension byte)
+                    const uint32_t last = n - 16;
+                    for (uint32_t o = 0;; o += 16) {
                         const uint32_t oo = min(o, last);
-                        *(par_u64u *)&L.ring[dA + oo] = *(const par_u64u *)&L.win[sA + oo];
+                        *(par_v4u *)&L.ring[dA + oo] = *(const par_v4u *)&L.win[sA + oo];
                         if (o >= last) break;
+                    }
+                } else if (n > 8) {
+                    // 9..16 literals in ONE round trip: a 16-byte chunk when its tail may fall into my own match
+                    // area (written afterwards), else two 8-byte chunks, the second re-anchored at the end
+                    if (n + ml >= 16) {
+                        *(par_v4u *)&L.ring[dA] = *(const par_v4u *)&L.win[sA];
+                    } else {
+                        const uint64_t a = *(const par_u64u *)&L.win[sA], b = *(const par_u64u *)&L.win[sA + n - 8];
+                        *(par_u64u *)&L.ring[dA] = a;
+                        *(par_u64u *)&L.ring[dA + n - 8] = b;
                     }
                 } else if (n > 0) {
                     const uint64_t v = lds_u64_any(L.win, sA);  // aligned reads + funnel
