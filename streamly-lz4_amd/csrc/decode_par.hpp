@@ -575,10 +575,22 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const int newBase = (op - PAR_HIST) & ~15;
                 const int delta = newBase - ringBase;
                 const int n16 = (op - newBase + (int)A + 15) >> 4;
-                for (int k = lane; k < n16; k += LZ4_WAVE) {
-                    const uint4 v = *(const uint4 *)&L.ring[delta + 16 * k];
+                // history + the alignment head: at most PAR_HIST + 31 bytes, i.e. three chunks per lane at the most;
+                // all of them are read before the first is written (one LDS round trip, and the ranges may overlap)
+                static_assert(PAR_HIST + 32 <= 3 * 16 * LZ4_WAVE, "the slide moves at most three chunks per lane");
+                {
+                    uint4 v[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int k = lane + i * LZ4_WAVE;
+                        v[i] = (k < n16) ? *(const uint4 *)&L.ring[delta + 16 * k] : make_uint4(0u, 0u, 0u, 0u);
+                    }
                     wave_fence();
-                    *(uint4 *)&L.ring[16 * k] = v;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int k = lane + i * LZ4_WAVE;
+                        if (k < n16) *(uint4 *)&L.ring[16 * k] = v[i];
+                    }
                 }
                 ringBase = newBase;
                 wave_fence();
