@@ -387,7 +387,7 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 struct TolLds { ParLds p; TolCtx t; };
 
 // (its out-of-line callee is decode_seq_run_tol, which no other kernel calls: the register bound can be its own)
-__global__ __launch_bounds__(64, 3) void k_decode_tolerant(DecodeArgs a)
+__global__ __launch_bounds__(64, 4) void k_decode_tolerant(DecodeArgs a)
 {
     __shared__ TolLds lds;
     const int blk = a.segFirst + (int)blockIdx.x;
