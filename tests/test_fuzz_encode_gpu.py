@@ -73,3 +73,37 @@ def test_encode_fuzz_structured(engine, oracle, accel):
         finally:
             engine.set_decoder(0)
         assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
+
+
+@pytest.mark.parametrize("accel", [1, 3, 400])
+def test_encode_fuzz_linked(engine, oracle, accel):
+    """The same ragged batch compressed as ONE linked stream (previous block = dictionary whenever it is non-empty and
+    lies directly in front): every block decodes through the oracle's linked decoder, block by block with the output
+    of the last non-empty block as dictionary, to exactly its input; the GPU's linked decode agrees; and blocks that
+    repeat their predecessor's content do reach into it."""
+    n_cases = int(os.environ.get("ENC_FUZZ_CASES", "400"))
+    rng = random.Random(7000 + accel)
+    blocks = [_make(rng, oracle, t) for t in range(n_cases)]
+    for t in range(5, n_cases, 9):                                  # neighbours that share content
+        blocks[t] = (blocks[t - 1][-3000:] + blocks[t])[: max(len(blocks[t]), 64)]
+    engine.set_linked_compress(True)
+    try:
+        fr, flen = engine.compress_batch(blocks, accel=accel)
+    finally:
+        engine.set_linked_compress(False)
+    assert len(fr) == sum(flen)
+    pos, dict_bytes, reached_back = 0, None, 0
+    for i, (b, f) in enumerate(zip(blocks, flen)):
+        c = int.from_bytes(fr[pos:pos + 4], "little")
+        assert c == f - 8 and int.from_bytes(fr[pos + 4:pos + 8], "little") == len(b)
+        assert 0 < c <= oracle.compress_bound(len(b)), (i, len(b), c)
+        code, out = oracle.decompress_block(fr[pos + 8:pos + f], len(b), dict_bytes)
+        assert code == len(b) and out == b, (i, len(b), code)
+        if dict_bytes and oracle.decompress_block(fr[pos + 8:pos + f], len(b))[0] != len(b):
+            reached_back += 1
+        if len(b) > 0:
+            dict_bytes = b
+        pos += f
+    assert reached_back >= n_cases // 20
+    out, blen = engine.decompress_batch(fr, linked=True)
+    assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
