@@ -315,31 +315,38 @@ def main():
         do_compress()
         eng.synchronize()
         fl = flen.clone()
-        gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)     # untimed: sets up the peer connections
-        del gathered
-        barrier()
-        g0 = time.perf_counter()
-        gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)
-        barrier()
-        gather_s = time.perf_counter() - g0
-        gather = {"ms": round(gather_s * 1e3, 3)}
-        if rank == 0:
-            # the gathered stream must decode to the generator's GLOBAL stream (block k = generator block k)
-            nG = NB * world
-            gsrc = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
-            eng.generate(kind, gsrc, BL, nG, first_block=0, block_step=1)
-            gout = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
-            gres = torch.empty(nG, dtype=torch.int32, device=dev)
-            gooff = torch.arange(nG + 1, dtype=torch.int64, device=dev) * BL
-            eng.decompress_batch_device(gathered, int(goff[-1].item()), goff, nG, gout, gooff, gres)
-            eng.synchronize()
-            ok = bool((gres == BL).all().item()) and torch.equal(gout, gsrc)
-            gather["verified"] = ok
-            gather["bytes"] = int(goff[-1].item())
-            if not ok:
-                sys.exit("bench.py: the gathered stream does not decode to the generator's global stream")
-            del gsrc, gout, gres, gooff
-        del gathered
+        # `value` does not depend on the gather: a failure in it (it is the only place where ranks exchange data) is
+        # reported in the line instead of taking the measurement down with it
+        try:
+            gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)     # untimed: sets up the peer connections
+            del gathered
+            barrier()
+            g0 = time.perf_counter()
+            gathered, goff = gather_ordered(dense[:Cbytes], fl, root=0, engine=eng)
+            barrier()
+            gather_s = time.perf_counter() - g0
+            gather = {"ms": round(gather_s * 1e3, 3)}
+            if rank == 0:
+                # the gathered stream must decode to the generator's GLOBAL stream (block k = generator block k)
+                nG = NB * world
+                gsrc = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
+                eng.generate(kind, gsrc, BL, nG, first_block=0, block_step=1)
+                gout = torch.empty(nG * BL, dtype=torch.uint8, device=dev)
+                gres = torch.empty(nG, dtype=torch.int32, device=dev)
+                gooff = torch.arange(nG + 1, dtype=torch.int64, device=dev) * BL
+                eng.decompress_batch_device(gathered, int(goff[-1].item()), goff, nG, gout, gooff, gres)
+                eng.synchronize()
+                ok = bool((gres == BL).all().item()) and torch.equal(gout, gsrc)
+                gather["verified"] = ok
+                gather["bytes"] = int(goff[-1].item())
+                if not ok:
+                    sys.exit("bench.py: the gathered stream does not decode to the generator's global stream")
+                del gsrc, gout, gres, gooff
+            del gathered
+        except SystemExit:
+            raise
+        except Exception as e:                                            # noqa: BLE001
+            gather = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
 
     if rank != 0:
         if dist is not None:
@@ -427,7 +434,7 @@ def main():
     if gather is not None:
         # compute-only is `value`; compute+gather adds one ordered gather per compress pass
         cm = (extra or {}).get("kernels_ms", {}).get("compress")
-        if cm:
+        if cm and "ms" in gather:
             gather["compress_only_GBps"] = round(world * U / cm / 1e6, 2)
             gather["compress_plus_gather_GBps"] = round(world * U / (cm + gather["ms"]) / 1e6, 2)
         line["gather"] = gather
