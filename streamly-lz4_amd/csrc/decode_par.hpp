@@ -260,8 +260,11 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
             // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
             // one 8-lane gather per group instead of two more squarings of all 512 nodes.
+#ifndef PAR_SQ
+#define PAR_SQ 3            // squaring rounds: the chain is then followed in groups of 2^PAR_SQ lanes
+#endif
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < PAR_SQ; k++) {
                 const int d = 1 << k;
                 const int cj = (int)*(const uint16_t *)(jumpB + c2);
 #pragma unroll
@@ -269,19 +272,29 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 int sh;
                 if (k == 0) sh = par_row_shr<1>(cj);
                 else if (k == 1) sh = par_row_shr<2>(cj);
-                else sh = par_row_shr<4>(cj);
+                else if (k == 2) sh = par_row_shr<4>(cj);
+                else sh = par_row_shr<8>(cj);
                 if (lane >= d && lane < 2 * d) c2 = (uint32_t)sh;
                 wave_fence();
                 *(uint4 *)&L.jump[8 * lane] =
                     make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
                 wave_fence();
             }
+            {
+                constexpr int G = 1 << PAR_SQ;
 #pragma unroll
-            for (int g = 1; g < 8; g++) {
-                int cj = PAR_END;
-                if (lane >= 8 * (g - 1) && lane < 8 * g) cj = (int)*(const uint16_t *)(jumpB + c2);
-                const int sh = (g & 1) ? par_row_shr<8>(cj) : par_bperm(cj, (lane - 8) & 63);
-                if (lane >= 8 * g && lane < 8 * g + 8) c2 = (uint32_t)sh;
+                for (int g = 1; g < LZ4_WAVE / G; g++) {
+                    int cj = PAR_END;
+                    if (lane >= G * (g - 1) && lane < G * g) cj = (int)*(const uint16_t *)(jumpB + c2);
+                    int sh;
+                    // the next group sits G lanes up: a DPP row shift while that stays inside a row of 16 lanes
+                    if (G == 1 && (g & 15)) sh = par_row_shr<1>(cj);
+                    else if (G == 2 && (g & 7)) sh = par_row_shr<2>(cj);
+                    else if (G == 4 && (g & 3)) sh = par_row_shr<4>(cj);
+                    else if (G == 8 && (g & 1)) sh = par_row_shr<8>(cj);
+                    else sh = par_bperm(cj, (lane - G) & 63);
+                    if (lane >= G * g && lane < G * g + G) c2 = (uint32_t)sh;
+                }
             }
             lap(PS_T_CHAIN);
 
