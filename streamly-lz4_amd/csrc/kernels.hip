@@ -727,7 +727,8 @@ static unsigned ptr_grid(int n) { return (unsigned)((n + 8 * PTR_RUN - 1) / (8 *
 __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsigned items)
 {
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
-    if (pass > 0 && !ctl->changed[pass - 1]) return;
+    // passes behind the first: only if the chasing fetch left something, and the pass before changed something
+    if (pass > 0 && !(ctl->changed[PTR_MAX_PASSES] && ctl->changed[pass - 1])) return;
     uint32_t *P = a.ptr;
     bool open = false;
     int lastBlk = -1;
@@ -823,57 +824,96 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsign
     }
 }
 
-// Every deferred byte is fetched from its root; the block's result becomes its size.
-__global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a)
+// Every deferred byte is fetched from its root.  CHASE: the fetch that runs right behind the FIRST jump pass finishes
+// what that pass left open by following those chains itself (up to PTR_JUMPS + 1 pointers, nothing written back): on
+// shallow data -- text is done after one pass and a few hops -- no further pass over the pointers is needed.  A byte it
+// cannot resolve raises PtrCtl::changed[PTR_MAX_PASSES]: only then do the remaining jump passes and the plain fetch
+// behind them run.
+template <bool CHASE>
+__global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
 {
-    int blkRel, part;
-    ptr_map(blockIdx.x, blkRel, part);
-    const int blk = a.segFirst + blkRel;
-    if (blk >= a.segEnd || !ptr_taken(a, blk)) return;
+    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
+    if (!CHASE && !ctl->changed[PTR_MAX_PASSES]) return;
     const uint32_t *P = a.ptr;
     const uint64_t lo = ptr_lo(a);
-    const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
-    const int size = a.tolSize[blk];
-    const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
-    const int x0 = part * per, x1 = min(size, x0 + per);
-    uint8_t *dst = a.out + a.outOff[blk];
     const uint8_t *outLo = a.out + lo;
     const uint8_t *dictTail = a.dict0 ? a.dict0 + a.dict0Len : nullptr;      // index PTR_PRE - d is dictTail[-d]
     auto root = [&](uint32_t e) -> uint8_t {
         return (e >= PTR_PRE) ? outLo[e - PTR_PRE] : dictTail[(int)e - (int)PTR_PRE];
     };
-    if (((bLo | (uint32_t)x0) & 3u) == 0) {
-        // four bytes per thread: one 16-byte load of pointers, up to four byte fetches, one 4-byte store
-        const uint4 *P4 = (const uint4 *)(P + bLo);
-        const int q1 = x1 >> 2;
-        for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
-            uint4 v = P4[q];
-            v.x &= ~PTR_FINAL; v.y &= ~PTR_FINAL; v.z &= ~PTR_FINAL; v.w &= ~PTR_FINAL;
-            const uint32_t self = bLo + 4u * (uint32_t)q;
-            const bool m0 = v.x != self, m1 = v.y != self + 1u, m2 = v.z != self + 2u, m3 = v.w != self + 3u;
-            if (!(m0 || m1 || m2 || m3)) continue;
-            uint32_t w;
-            if (m0 && m1 && m2 && m3 && v.x >= PTR_PRE && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
-                __builtin_memcpy(&w, outLo + (v.x - PTR_PRE), 4);          // four neighbouring roots: one request
-            } else {
-                __builtin_memcpy(&w, dst + 4 * q, 4);
-                if (m0) w = (w & 0xffffff00u) | (uint32_t)root(v.x);
-                if (m1) w = (w & 0xffff00ffu) | ((uint32_t)root(v.y) << 8);
-                if (m2) w = (w & 0xff00ffffu) | ((uint32_t)root(v.z) << 16);
-                if (m3) w = (w & 0x00ffffffu) | ((uint32_t)root(v.w) << 24);
+    bool unresolved = false;
+    auto follow = [&](uint32_t e) -> uint32_t {                     // CHASE, one byte: the root, or an open pointer
+#pragma unroll 1
+        for (int k = 0; k <= PTR_JUMPS && !(e & PTR_FINAL); k++) e = P[e];
+        if (!(e & PTR_FINAL)) unresolved = true;
+        return e;
+    };
+    for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+        int blkRel, part;
+        ptr_map(item, blkRel, part);
+        const int blk = a.segFirst + blkRel;
+        if (blk >= a.segEnd || !ptr_taken(a, blk)) continue;
+        const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
+        const int size = a.tolSize[blk];
+        const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
+        const int x0 = part * per, x1 = min(size, x0 + per);
+        uint8_t *dst = a.out + a.outOff[blk];
+        if (((bLo | (uint32_t)x0) & 3u) == 0) {
+            // four bytes per thread: one 16-byte load of pointers, up to four byte fetches, one 4-byte store
+            const uint4 *P4 = (const uint4 *)(P + bLo);
+            const int q1 = x1 >> 2;
+            for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
+                uint4 v = P4[q];
+                if (CHASE && !((v.x & v.y & v.z & v.w) & PTR_FINAL)) {
+#pragma unroll 1
+                    for (int k = 0; k <= PTR_JUMPS; k++) {
+                        const bool o0 = !(v.x & PTR_FINAL), o1 = !(v.y & PTR_FINAL), o2 = !(v.z & PTR_FINAL), o3 = !(v.w & PTR_FINAL);
+                        if (!(o0 || o1 || o2 || o3)) break;
+                        if (o0 && o1 && o2 && o3 && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
+                            uint4 w;
+                            __builtin_memcpy(&w, P + v.x, 16);            // neighbours: one request for the four
+                            v = w;
+                        } else {
+                            const uint32_t n0 = o0 ? P[v.x] : v.x, n1 = o1 ? P[v.y] : v.y, n2 = o2 ? P[v.z] : v.z, n3 = o3 ? P[v.w] : v.w;
+                            v.x = n0; v.y = n1; v.z = n2; v.w = n3;
+                        }
+                    }
+                    if (!((v.x & v.y & v.z & v.w) & PTR_FINAL)) { unresolved = true; continue; }
+                }
+                v.x &= ~PTR_FINAL; v.y &= ~PTR_FINAL; v.z &= ~PTR_FINAL; v.w &= ~PTR_FINAL;
+                const uint32_t self = bLo + 4u * (uint32_t)q;
+                const bool m0 = v.x != self, m1 = v.y != self + 1u, m2 = v.z != self + 2u, m3 = v.w != self + 3u;
+                if (!(m0 || m1 || m2 || m3)) continue;
+                uint32_t w;
+                if (m0 && m1 && m2 && m3 && v.x >= PTR_PRE && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
+                    __builtin_memcpy(&w, outLo + (v.x - PTR_PRE), 4);          // four neighbouring roots: one request
+                } else {
+                    __builtin_memcpy(&w, dst + 4 * q, 4);
+                    if (m0) w = (w & 0xffffff00u) | (uint32_t)root(v.x);
+                    if (m1) w = (w & 0xffff00ffu) | ((uint32_t)root(v.y) << 8);
+                    if (m2) w = (w & 0xff00ffffu) | ((uint32_t)root(v.z) << 16);
+                    if (m3) w = (w & 0x00ffffffu) | ((uint32_t)root(v.w) << 24);
+                }
+                __builtin_memcpy(dst + 4 * q, &w, 4);
             }
-            __builtin_memcpy(dst + 4 * q, &w, 4);
-        }
-        for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
-            const uint32_t self = bLo + (uint32_t)x, e = P[self] & ~PTR_FINAL;
-            if (e != self) dst[x] = root(e);
-        }
-    } else {
-        for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
-            const uint32_t self = bLo + (uint32_t)x, e = P[self] & ~PTR_FINAL;
-            if (e != self) dst[x] = root(e);
+            for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) {
+                const uint32_t self = bLo + (uint32_t)x;
+                uint32_t e = P[self];
+                if (CHASE) { e = follow(e); if (!(e & PTR_FINAL)) continue; }
+                e &= ~PTR_FINAL;
+                if (e != self) dst[x] = root(e);
+            }
+        } else {
+            for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) {
+                const uint32_t self = bLo + (uint32_t)x;
+                uint32_t e = P[self];
+                if (CHASE) { e = follow(e); if (!(e & PTR_FINAL)) continue; }
+                e &= ~PTR_FINAL;
+                if (e != self) dst[x] = root(e);
+            }
         }
     }
+    if (CHASE && __syncthreads_or(unresolved ? 1 : 0) && threadIdx.x == 0) ctl->changed[PTR_MAX_PASSES] = 1u;
 }
 
 // ... and only then do the results change: the passes above tell a dependent block by its standalone result.
@@ -919,9 +959,13 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
         // (the stream flags follow the control block: a stream turned down in one segment gets its chance in the next)
         hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
         hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
-        for (int pass = 0; pass < PTR_MAX_PASSES; pass++)
-            hipLaunchKernelGGL(k_ptr_jump, dim3(pass == 0 ? ptr_grid(n) : std::min(ptr_grid(n), 4096u)), dim3(256), 0, s, a, pass, ptr_grid(n));
-        hipLaunchKernelGGL(k_ptr_fetch, dim3(ptr_grid(n)), dim3(256), 0, s, a);
+        const unsigned items = ptr_grid(n), few = std::min(items, 4096u);
+        hipLaunchKernelGGL(k_ptr_jump, dim3(items), dim3(256), 0, s, a, 0, items);
+        hipLaunchKernelGGL(k_ptr_fetch<true>, dim3(items), dim3(256), 0, s, a, items);
+        // (what follows usually finds nothing to do: small grids that stride over the items)
+        for (int pass = 1; pass < PTR_MAX_PASSES; pass++)
+            hipLaunchKernelGGL(k_ptr_jump, dim3(few), dim3(256), 0, s, a, pass, items);
+        hipLaunchKernelGGL(k_ptr_fetch<false>, dim3(few), dim3(256), 0, s, a, items);
         hipLaunchKernelGGL(k_ptr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     }
     // whatever the pass above did not take (ptrBad, or no pool): the walk, block after block
