@@ -705,6 +705,10 @@ __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 #ifndef PTR_RUN
 #define PTR_RUN 16
 #endif
+#ifndef PTR_CHASE
+#define PTR_CHASE 32                // pointers the chasing fetch follows before it gives a byte up (12: an engine-written
+                                   // linked text stream keeps needing the passes, 44 instead of 59 GB/s; 96: as 32)
+#endif
 #ifndef PTR_ILP
 #define PTR_ILP 1                  // groups per thread advancing in lock step: more requests in flight LOSE (2: -8 %, 4: -15 %),
 #endif                             // the passes are bound by the number of scattered requests, not by their latency
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsign
 }
 
 // Every deferred byte is fetched from its root.  CHASE: the fetch that runs right behind the FIRST jump pass finishes
-// what that pass left open by following those chains itself (up to PTR_JUMPS + 1 pointers, nothing written back): on
+// what that pass left open by following those chains itself (up to PTR_CHASE pointers, nothing written back): on
 // shallow data -- text is done after one pass and a few hops -- no further pass over the pointers is needed.  A byte it
 // cannot resolve raises PtrCtl::changed[PTR_MAX_PASSES]: only then do the remaining jump passes and the plain fetch
 // behind them run.
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
     bool unresolved = false;
     auto follow = [&](uint32_t e) -> uint32_t {                     // CHASE, one byte: the root, or an open pointer
 #pragma unroll 1
-        for (int k = 0; k <= PTR_JUMPS && !(e & PTR_FINAL); k++) e = P[e];
+        for (int k = 0; k < PTR_CHASE && !(e & PTR_FINAL); k++) e = P[e];
         if (!(e & PTR_FINAL)) unresolved = true;
         return e;
     };
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
                 uint4 v = P4[q];
                 if (CHASE && !((v.x & v.y & v.z & v.w) & PTR_FINAL)) {
 #pragma unroll 1
-                    for (int k = 0; k <= PTR_JUMPS; k++) {
+                    for (int k = 0; k < PTR_CHASE; k++) {
                         const bool o0 = !(v.x & PTR_FINAL), o1 = !(v.y & PTR_FINAL), o2 = !(v.z & PTR_FINAL), o3 = !(v.w & PTR_FINAL);
                         if (!(o0 || o1 || o2 || o3)) break;
                         if (o0 && o1 && o2 && o3 && v.y == v.x + 1u && v.z == v.x + 2u && v.w == v.x + 3u) {
