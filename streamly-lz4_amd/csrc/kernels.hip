@@ -86,12 +86,12 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 // K2: encode
 // ---------------------------------------------------------------------------
 // MOD: table entries are positions modulo 64 Ki (encode_wave.hpp, tab_candidate): needed when positions run beyond
-// 64 Ki -- blocks above 64 KiB, or a dictionary in front of the block (linked compression).  The table is 8 KiB
-// either way, so every block size runs at 20 waves per CU (a table of 32-bit positions would halve that).
+// 64 Ki -- blocks above 64 KiB, or a dictionary in front of the block (linked compression).  The table is the same
+// size either way, so every block size runs at the same occupancy (a table of 32-bit positions would halve it).
 template <bool MOD>
 __global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
 {
-    __shared__ uint16_t table[4096];
+    __shared__ uint16_t table[ENC_TABLE_ENTRIES];           // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU
     const int blk = (int)blockIdx.x;
     const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
     const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
