@@ -88,8 +88,11 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 // MOD: table entries are positions modulo 64 Ki (encode_wave.hpp, tab_candidate): needed when positions run beyond
 // 64 Ki -- blocks above 64 KiB, or a dictionary in front of the block (linked compression).  The table is the same
 // size either way, so every block size runs at the same occupancy (a table of 32-bit positions would halve it).
+#ifndef ENC_WAVES_PER_EU
+#define ENC_WAVES_PER_EU 4
+#endif
 template <bool MOD>
-__global__ __launch_bounds__(64) void k_encode(EncodeArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, ENC_WAVES_PER_EU))) void k_encode(EncodeArgs a)
 {
     __shared__ uint16_t table[ENC_TABLE_ENTRIES];           // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU
     const int blk = (int)blockIdx.x;
