@@ -16,6 +16,8 @@ static int TAGBITS = 4;        // bits of tag compared
 static int DEPTH = 2;          // pipe: windows in flight
 static int BACKCAP = 8;        // head measures up to 8 bytes before itself
 static int WIN = 64;
+static int END2 = 0;           // cur: also register (match end - 2), as the reference does (:1146)
+static int MINC = 0;           // cur: candidates below this position are not taken
 static long g_windows, g_heads, g_seqs, g_hits, g_ext2, g_hist[65], g_known;
 
 typedef struct { uint16_t pos; uint8_t tag; uint8_t used; } Ent;
@@ -55,7 +57,7 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                     if (!valid[l]) continue;
                     uint32_t hx = hash16(src + pos); h[l] = hx >> 8; tg[l] = (hx >> (8 - TAGBITS)) & tmask;
                     cand[l] = table[h[l]].pos;
-                    candOk[l] = cand[l] < (uint32_t)pos && (table[h[l]].tag & tmask) == tg[l];
+                    candOk[l] = cand[l] < (uint32_t)pos && (table[h[l]].tag & tmask) == tg[l] && cand[l] >= (uint32_t)MINC;
                     if (!table[h[l]].used && cand[l] == 0 && pos > 0) candOk[l] = (0 == tg[l]);   // zeroed table: tag 0, pos 0
                 }
                 int hd = 0;
@@ -71,7 +73,7 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                             int m = count_fwd(src, pos, cand[l], matchlimit);
                             ml[l] = m < maxLen ? m : maxLen;
                             int b = 0;
-                            if (cand[l] >= 8) while (b < BACKCAP && src[pos - 1 - b] == src[cand[l] - 1 - b]) b++;
+                            if (cand[l] >= 8) while (b < BACKCAP && b < (int)cand[l] && src[pos - 1 - b] == src[cand[l] - 1 - b]) b++;
                             hback[l] = b;
                         }
                     }
@@ -105,7 +107,8 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                     // covered: strictly inside a selected match
                     int covered = 0;
                     for (int q = l - 1; q >= 0; q--) if (sel[q]) { covered = pos < p0 + q + (int)ml[q]; break; }
-                    if (valid[l] && !covered && pos < nextP) { table[h[l]].pos = (uint16_t)pos; table[h[l]].tag = tg[l]; table[h[l]].used = 1; }
+                    int end2 = 0; if (END2) for (int q = l - 1; q >= 0; q--) if (sel[q]) { end2 = pos == p0 + q + (int)ml[q] - 2; break; }
+                    if (valid[l] && (!covered || end2) && pos < nextP) { table[h[l]].pos = (uint16_t)pos; table[h[l]].tag = tg[l]; table[h[l]].used = 1; }
                     if (sel[l]) {
                         int mstart = pos, mcand = (int)cand[l];
                         int room = mstart - prevEnd; if (mcand < room) room = mcand;
@@ -263,6 +266,9 @@ int main(int argc, char **argv)
     printf("  %-34s ratio %.4f  windows/blk %.0f heads/win %.1f hits/win %.2f seqs/blk %.0f long(>56)/win %.2f\n", label, (double)nb * bl / s, \
         (double)g_windows / nb, (double)g_heads / (g_windows ? g_windows : 1), (double)g_hits / (g_windows ? g_windows : 1), (double)g_seqs / nb, (double)g_ext2 / (g_windows ? g_windows : 1)); } while (0)
     TAGBITS = 4; RUN("cur tag4", sim_cur(blocks[b], bl, 1));
+    TAGBITS = 4; END2 = 1; RUN("cur tag4 +end2", sim_cur(blocks[b], bl, 1)); END2 = 0;
+    TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
+    TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)

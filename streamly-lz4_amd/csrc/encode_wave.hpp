@@ -39,19 +39,28 @@ __device__ __forceinline__ uint32_t hash5(uint64_t v)
 {
     return (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 12));
 }
-// The next EIGHT bits of the same product are kept beside the position as a TAG (one byte per bucket, behind the
-// table): a candidate whose tag differs is not read.  With the reference's insertion policy most table entries a
-// probe meets are unrelated older positions; their verification reads were 23x the input in HBM fetches (47 scattered
-// reads per 64-position window for 2.4 matches).  Round 2 kept four bits (nibbles, two LDS atomics per update);
-// round 3 keeps a byte: a tag is then read and written with plain byte accesses (the pipelined finder below writes
-// every tag twice when it takes an insertion back), a candidate that passes is a real match 99 times in 100, so the
-// finder skips the separate verification round trip.  12 KiB of LDS per wave: 13 waves per CU.
-__device__ __forceinline__ uint32_t hash5x(uint64_t v) { return (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 20)); }
-#define ENC_TABLE_ENTRIES (4096 + 2048)        /* 16-bit units: 4096 positions + 4096 tag bytes */
-#define ENC_TAG_DECL uint8_t *tags = (uint8_t *)(table + 4096);
-#define ENC_HT(v, h, t) const uint32_t hx_ = hash5x(v); h = hx_ >> 8; t = hx_ & 255u
-#define ENC_TAG_OK(h, t) ((uint32_t)tags[h] == (t))
-#define ENC_TAG_SET(h, t) tags[h] = (uint8_t)(t)
+// The next four bits of the same product are kept beside the position as a TAG: a candidate whose tag differs is not
+// read.  With the reference's insertion policy most table entries a probe meets are unrelated older positions; their
+// verification reads were 23x the input in HBM fetches (47 scattered reads per 64-position window for 2.4 matches).
+// Four bits remove 15 of 16 of them (run heads per window 47 -> 16 on lzsynth, 61 -> 17 on text); a candidate that
+// passes is a real match nine times in ten, which is what lets the pipelined finder below skip the separate
+// verification round trip.  Tags are nibbles behind the table (table + 4096 entries), eight per 32-bit word, written
+// with two LDS atomics (and, or): two lanes that update different nibbles of one word in the same instruction both
+// land, two lanes on the same bucket leave the tag of one of them.  10 KiB of LDS per wave: 16 waves per CU.  (A byte
+// per tag -- plain stores -- was measured in round 3: 12 KiB, 13 waves per CU, and the rate follows the wave count.)
+__device__ __forceinline__ uint32_t hash5x(uint64_t v) { return (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 16)); }
+__device__ __forceinline__ uint32_t tag_get(const uint32_t *tags, uint32_t h) { return (tags[h >> 3] >> ((h & 7u) * 4u)) & 15u; }
+__device__ __forceinline__ void tag_set(uint32_t *tags, uint32_t h, uint32_t t)
+{
+    const uint32_t sh = (h & 7u) * 4u;
+    atomicAnd(&tags[h >> 3], ~(15u << sh));
+    atomicOr(&tags[h >> 3], t << sh);
+}
+#define ENC_TABLE_ENTRIES (4096 + 1024)        /* 16-bit units: 4096 positions + 4096 nibbles */
+#define ENC_TAG_DECL uint32_t *tags = (uint32_t *)(table + 4096);
+#define ENC_HT(v, h, t) const uint32_t hx_ = hash5x(v); h = hx_ >> 4; t = hx_ & 15u
+#define ENC_TAG_OK(h, t) (tag_get(tags, h) == (t))
+#define ENC_TAG_SET(h, t) tag_set(tags, h, t)
 
 // Emit a length >= 15 continuation (rest = len - 15): rest/255 bytes of 255 then rest%255.
 __device__ __forceinline__ uint8_t *emit_ext_len(uint8_t *op, uint32_t rest)
@@ -120,16 +129,24 @@ __device__ __forceinline__ uint32_t enc_mbcnt(uint64_t m)      // set bits of m 
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// One 64-position window of the pipelined finder between its probe (stage A) and its finish (stage C).
-struct PipeWin {
-    int p0;             // first position (wave-uniform)
-    uint32_t hk;        // bucket | candOk << 30 | probed << 31
-    uint32_t olde;      // what the bucket held before this window wrote itself there: position | tag << 16
-    uint32_t cand;      // candidate position (candOk lanes)
-    uint64_t headm;     // run heads (wave-uniform)
-    uint32_t g0, g1;    // per lane group of four: valid << 31 | head lane << 25 | candidate; two rounds of 16 heads
-    dev_v4 a0, b0, a1, b1;   // 16 bytes at the head's position / at its candidate, per group lane and round
-};
+// inclusive wave max-scan (unsigned) with DPP
+__device__ __forceinline__ uint32_t enc_scan_max(uint32_t x)
+{
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+// LDS word = (word & ~mask) | bits, one atomic instruction (ds_mskor_b32): a tag nibble is replaced without touching
+// its neighbours, whatever other lanes do to them in the same instruction
+__device__ __forceinline__ void lds_mskor(uint32_t *w, uint32_t mask, uint32_t bits)
+{
+    asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"((uint32_t)(uintptr_t)w), "v"(mask), "v"(bits) : "memory");
+}
 
 // diagnostics (ENC_STATS builds only): cycles per phase of the dense-window path
 #ifdef ENC_STATS
@@ -257,7 +274,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     // zero the table (positions are block-relative; 0 is a real position, as in the reference)
     {
         uint32_t *t32 = (uint32_t *)table;
-        const int nd = (int)(4096 * sizeof(TabT) / 4) + 1024;   // positions, then the tag bytes
+        const int nd = (int)(4096 * sizeof(TabT) / 4) + 512;    // positions, then the tags
         for (int i = lane; i < nd; i += LZ4_WAVE) t32[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -298,28 +315,28 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
 #ifndef ENC_NO_PIPE
         // ===================================================================================================
-        // Pipelined dense finder (round 3).  The dense-window code further down runs ONE window at a time and
-        // each window is a chain of dependent memory round trips (bytes -> table -> candidate -> extension
-        // steps -> selection -> insertion): a wave spends two thirds of its cycles waiting, on vectors that are
-        // nine lanes wide on average.  Here a window is cut into two stages and two windows are in flight:
-        //   stage A (probe)  : hash the 64 positions, read the buckets, WRITE every probed position into its
-        //                      bucket at once (the bucket's previous entry is kept in a register), find the run
-        //                      heads and hand every head to a group of four lanes that requests the 16 bytes
-        //                      per lane around the head's position and around its candidate: 8 bytes before
-        //                      (catch up, :1019) and 56 after, in ONE round trip, every lane busy;
-        //   stage C (finish) : a window later, when those bytes are there: match lengths per group (quad DPP),
-        //                      greedy selection (as below), and every position that turns out to lie strictly
-        //                      inside a selected match takes its insertion back if the bucket still holds it
-        //                      (the reference never registers those positions, :1146-1159: with them the table
-        //                      forgets far matches, text ratio 1.84 -> 1.78).
-        // Windows sit on a fixed grid (the next window starts 64 positions on, not at the end of the last
-        // match), so stage A of window w+1 needs nothing stage C of window w computes except the table, and the
-        // table is right up to positions inside the matches of ONE window, for the length of ONE window
-        // (oracle/sim_encode2.c: lzsynth 2.915 against 2.895 for the serial windows, text 1.841 against 1.838).
-        // A match that reaches the 56-byte horizon is extended by the whole wave, 1 KiB a step, only when it is
-        // selected.  The region ends where a window's requests could pass the end of the input, or when a
-        // window selects nothing (the miss counter then widens the stride, as in the reference): the windows
-        // in flight are finished and the code below takes over.
+        // Dense window, one round trip (round 3).  Round 2's window (the code further down, still used for the
+        // last windows of a block) is a chain of dependent memory round trips -- bytes -> table -> candidate ->
+        // one to three extension steps per run head, in per-lane loops -- and a wave spent two thirds of its
+        // cycles waiting.  Here every run head is handed to a GROUP OF FOUR LANES that requests, in one go,
+        // 16 bytes per lane around the head's position and around its candidate: the 8 bytes before them
+        // (catch up, :1019) and the 56 after.  The tags make a candidate a real match nine times in ten, so
+        // there is no separate verification step: one round trip per window, every lane busy, and the lengths
+        // of up to 32 heads come out of two quad-DPP reductions.  A match that reaches the 56-byte horizon is
+        // extended by the whole wave, 1 KiB a step, and only if the greedy selection takes it.
+        //   A (probe)   hash the 64 positions, read buckets and tags, run heads, groups, requests
+        //   C (finish)  lengths per group, every lane learns its run's head (DPP max-scan), greedy selection
+        //               (scalar, as below), the probed positions outside the selected matches go into the table
+        //               (:998, the reference's policy), sequences are queued
+        // The next window starts at the end of the last selected match; its bytes are requested as soon as
+        // the selection knows that position.
+        // Measured on the way (MI355X, lzsynth / text, 16 384 blocks): two windows in flight per wave (window
+        // w+1 probed before window w is finished, on a fixed 64-position grid, every probed position written
+        // into the table at once and positions that turn out to lie inside a selected match taking their
+        // insertion back a window later; oracle/sim_encode2.c has the policy: ratio 2.915 / 1.841 against
+        // 2.895 / 1.838) 132 / 112 GB/s; one window at a time, this code, 150 / 109 GB/s: the fixed grid
+        // costs 17 % more windows (1022 against 875 per block) and a window costs its ~200 vector
+        // instructions whatever is in flight -- at 16 waves per CU the vector ALU is 80 % busy either way.
         // ===================================================================================================
         const LZ4_GLOBAL uint8_t *gsrc = as_global(src);
         auto load16 = [&](int off) -> dev_v4 { return *(const LZ4_GLOBAL dev_v4u *)(gsrc + (uint32_t)off); };
@@ -329,66 +346,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                  : ctrl == 2 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xaa, 0xf, 0xf, true)
                              : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xff, 0xf, 0xf, true);
         };
-        const uint64_t lowerIncl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
         const bool pipeFits = n <= (1 << 25);          // a group's head travels as a 25-bit position
+        // the last request of a window ends 136 bytes behind its first position
         auto pipe_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 + 136 <= n && pipeFits; };
-
-        // ---- stage A ----
-        auto stageA = [&](PipeWin &W, const int p0) {
-            W.p0 = p0;
-            const int myPos = p0 + lane;
-            const uint64_t v8 = (pfPos == p0) ? pfV8 : *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)myPos);
-            pfPos = p0 + LZ4_WAVE;
-            pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(pfPos + lane));      // p0 + 135 < n
-            const bool probe = myPos >= anchor;       // below the anchor known now: inside a match, not visited
-            uint32_t h, tg;
-            ENC_HT(v8, h, tg);
-            const uint32_t oldp = table[h], oldt = tags[h];
-            if (probe) { table[h] = (TabT)myPos; tags[h] = (uint8_t)tg; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            uint32_t cand = 0;
-            const bool candOk = probe && tab_candidate<TabT, DICT>((TabT)oldp, myPos, cand) && oldt == tg && cand >= 8u;
-            W.hk = h | ((uint32_t)candOk << 30) | ((uint32_t)probe << 31);
-            W.olde = oldp | (oldt << 16);
-            W.cand = cand;
-            // run heads: a candidate that continues its left neighbour's belongs to the same copied region
-            const uint32_t cv = candOk ? cand : 0xffffffffu;
-            const uint32_t prevCand = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool contin = candOk && prevCand != 0xffffffffu && cand == prevCand + 1u;
-            const bool head = candOk && !contin;
-            const uint64_t headm = __ballot(head);
-            W.headm = headm;
-            const uint32_t rank = enc_mbcnt(headm);
-            const uint32_t payload = 0x80000000u | ((uint32_t)lane << 25) | cand;      // positions stay below 2^25 (blocks <= 4 MiB + dictionary)
-            const int j16 = (lane & 3) * 16;
-            // round 0: heads 0..15, one per group of four lanes (lane 1 takes what the others send)
-            {
-                const int dest = (head && rank < 16u) ? (int)rank * 4 : 1;
-                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)payload), 0);
-                W.g0 = gi;
-                const bool gv = (gi >> 31) != 0u;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                W.a0 = load16(gv ? p0 + hl + j16 - 8 : p0);
-                W.b0 = load16(gv ? c + j16 - 8 : p0);
-            }
-            // round 1: heads 16..31 (one window in four has them); the requests go out either way, so that the
-            // number of requests in flight does not depend on the data (the waits are counted, not named)
-            {
-                int po = p0, co = p0;
-                uint32_t gi = 0;
-                if (headm >> 16 && __builtin_popcountll(headm) > 16) {
-                    const int dest = (head && (rank >> 4) == 1u) ? (int)(rank & 15u) * 4 : 1;
-                    gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)payload), 0);
-                    const bool gv = (gi >> 31) != 0u;
-                    const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                    if (gv) { po = p0 + hl + j16 - 8; co = c + j16 - 8; }
-                }
-                W.g1 = gi;
-                W.a1 = load16(po);
-                W.b1 = load16(co);
-            }
-            ENC_LAP(0);
-        };
+        const uint32_t lanePay = 0x80000000u | ((uint32_t)lane << 25);   // a head's message to its group: valid | lane | candidate
+        const int j16m8 = (lane & 3) * 16 - 8;
 
         // match length of a group's head from the 4 x 16 bytes of the group (meaningful in the group's lane 0):
         // forward length (0..56) | equal bytes before the head (0..8) << 8 | four equal bytes << 12 | horizon reached << 13
@@ -410,7 +372,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             return total | (back << 8) | ((uint32_t)(f >= (uint32_t)LZ4_MINMATCH) << 12) | ((uint32_t)(total == 56u) << 13);
         };
 
-        // a selected match that reached the horizon: the whole wave counts on, 16 bytes a lane
+        // a match that reached the horizon: the whole wave counts on, 16 bytes a lane
         auto extend_long = [&](const int pe, const int ce) -> int {
             int total = 0;
             const int maxExtra = matchlimit - pe;
@@ -435,41 +397,79 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             return total;
         };
 
-        // ---- stage C ----
-        auto stageC = [&](PipeWin &W) {
-            const int p0 = W.p0;
+        // one window: positions [p0, p0 + 64), p0 >= anchor; returns where the next one starts
+        auto group_window = [&](const int p0) -> int {
+            // ---- A: probe ----
             const int myPos = p0 + lane;
-            const uint64_t headm = W.headm;
-            const bool head = (headm >> lane) & 1ull;
-            const uint32_t rank = enc_mbcnt(headm);
-            uint32_t r = (uint32_t)par_free_bperm((int)groupLen(W.a0, W.b0), (int)(rank & 15u) * 4);
-            if (headm >> 16 && __builtin_popcountll(headm) > 16) {
-                const uint32_t r1 = (uint32_t)par_free_bperm((int)groupLen(W.a1, W.b1), (int)(rank & 15u) * 4);
-                if (rank >= 16u) r = r1;
+            if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)myPos);
+            const uint32_t hx = hash5x(pfV8);
+            const uint32_t h = hx >> 4, tg = hx & 15u;
+            const uint32_t tsh = (hx >> 2) & 28u;                 // (h & 7) * 4
+            uint32_t *tagw = &tags[hx >> 7];                      // h >> 3
+            const uint32_t oldp = table[h], oldt = (*tagw >> tsh) & 15u;
+            uint32_t cand = 0;
+            const bool candOk = tab_candidate<TabT, DICT>((TabT)oldp, myPos, cand) && oldt == tg && cand >= 8u;
+            // run heads: a candidate that continues its left neighbour's belongs to the same copied region
+            // (a lane without a candidate sends ~0, and ~0 + 1 = 0 is no candidate: they start at 8)
+            const uint32_t cv = candOk ? cand : 0xffffffffu;
+            const uint32_t prevCand = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool head = candOk && cand != prevCand + 1u;
+            const uint64_t headm = __ballot(head);
+            const bool twoRounds = (headm >> 16) != 0ull && __builtin_popcountll(headm) > 16;
+            const uint32_t rank4 = enc_mbcnt(headm) << 4;         // byte address of lane 4 * rank
+            const uint32_t payload = lanePay | cand;              // positions stay below 2^25 (blocks <= 4 MiB + dictionary)
+            dev_v4 a0, b0, a1, b1;
+            // round 0: heads 0..15, one per group of four lanes (lane 1 takes what the others send)
+            {
+                const int dest = (head && rank4 < 256u) ? (int)rank4 : 4;
+                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)payload), 0);
+                const bool gv = (int)gi < 0;
+                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
+                a0 = load16(gv ? p0 + hl + j16m8 : p0);
+                b0 = load16(gv ? c + j16m8 : p0);
             }
-            if (!head || rank >= 32u) r = 0u;
+            // round 1: heads 16..31 (one window in four has them)
+            if (twoRounds) {
+                const int dest = (head && (rank4 >> 8) == 1u) ? (int)(rank4 & 255u) : 4;
+                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)payload), 0);
+                const bool gv = (int)gi < 0;
+                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
+                a1 = load16(gv ? p0 + hl + j16m8 : p0);
+                b1 = load16(gv ? c + j16m8 : p0);
+            }
+            ENC_LAP(0);
+            // ---- C: finish ----
+            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a0, b0));
+            if (twoRounds) {
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a1, b1));
+                if (rank4 >= 256u) r = r1;
+            }
 #ifdef ENC_STATS
             est[7] += (unsigned)__builtin_popcountll(headm);
 #endif
-            // the other lanes of a run derive from its head
-            const bool candOk = (W.hk >> 30) & 1u;
-            const uint64_t below = headm & lowerIncl;
-            const int myHead = below ? 63 - (int)__builtin_clzll(below) : 0;
-            const uint32_t hr = (uint32_t)par_free_bperm((int)r, myHead);
-            const int m0 = (int)(hr & 0xffu) - (lane - myHead);
-            const bool hit = candOk && ((hr >> 12) & 1u) && m0 >= LZ4_MINMATCH;
+            // every lane learns its run's head (lane and result) with a max-scan: head lanes put (lane + 1) << 16 | result
+            // in, the others 0, and the largest value at or below a lane belongs to the nearest head below it
+            const uint32_t hv = enc_scan_max(head ? (((uint32_t)lane + 1u) << 16) | (rank4 < 512u ? r : 0u) : 0u);   // heads beyond the 32nd: no match
+            const int delta = lane + 1 - (int)(hv >> 16);                 // lanes between my run's head and me
+            const int m0 = (int)(hv & 0xffu) - delta;
+            const bool hit = candOk && ((hv >> 12) & 1u) && m0 >= LZ4_MINMATCH;
             uint32_t myMl = hit ? (uint32_t)m0 : 0u;
-            const uint32_t hback = (hr >> 8) & 15u;
-            const uint32_t cand = W.cand;
             ENC_LAP(1);
-            // ---- greedy left-to-right selection, from the running anchor ----
-            uint64_t hitm = __ballot(hit);
-            const uint64_t capm = __ballot(hit && ((hr >> 13) & 1u));
-            const int anchor0 = anchor;
-            const int lowcut = anchor0 - p0;
-            if (lowcut > 0) hitm = (lowcut >= LZ4_WAVE) ? 0ull : (hitm & (~0ull << lowcut));
+            // ---- greedy left-to-right selection ----
+            const uint64_t hitm = __ballot(hit);
+            if (!hitm) {
+                // nothing here: every position is registered, the miss counter widens the stride (:957-967)
+                table[h] = (TabT)myPos;
+                lds_mskor(tagw, 15u << tsh, tg << tsh);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                missAcc += LZ4_WAVE;
+                pfPos = -1;
+                return p0 + LZ4_WAVE;
+            }
+            const uint64_t capm = __ballot(hit && ((hv >> 13) & 1u));
             uint64_t selm = 0;
-            int pEnd = anchor0;
+            int pEnd = anchor;
+            int prevEnd = anchor;              // end of the selected match before me (selected lanes: my literal start)
             for (uint64_t hm = hitm; hm;) {
                 const int k = (int)__builtin_ctzll(hm);
                 int len = __builtin_amdgcn_readlane((int)myMl, k);
@@ -480,34 +480,35 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 const int endk = p0 + k + len;
                 selm |= 1ull << k;
                 pEnd = endk;
+                if (lane > k) prevEnd = endk;
                 const int sh = endk - p0;
                 hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
             }
             const bool sel = (selm >> lane) & 1ull;
-            int prevEnd = anchor0;             // end of the selected match before me (selected lanes: my literal start)
-            {
-                const uint64_t mb = selm & (lowerIncl >> 1);
-                const int from = mb ? 63 - (int)__builtin_clzll(mb) : -1;
-                const int endFrom = par_free_bperm(myPos + (int)myMl, from & 63);
-                if (from >= 0) prevEnd = endFrom;
-            }
+            // the next window starts at the end of the last match, or where this one ends: its bytes are requested now
+            const int nextP = max(p0 + LZ4_WAVE, pEnd);
+            pfPos = nextP;
+            if (nextP + 72 <= n) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
+            else pfPos = -1;
             ENC_LAP(2);
-            // ---- positions strictly inside a selected match take their insertion back (:1146-1159) ----
-            if ((W.hk >> 31) && !sel && myPos < prevEnd) {
-                const uint32_t h = W.hk & 0xfffu;
-                if (table[h] == (TabT)myPos) { table[h] = (TabT)(W.olde & 0xffffu); tags[h] = (uint8_t)(W.olde >> 16); }
+            // ---- table: the probed positions outside the selected matches (:998) ----
+            if (sel || myPos >= prevEnd) {
+                table[h] = (TabT)myPos;
+                lds_mskor(tagw, 15u << tsh, tg << tsh);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
-            if (selm) {
-                // ---- catch up (:1019), bounded by the previous match ----
-                int mstart = myPos, mcand = (int)cand;
-                if (sel) {
-                    const int room = min(mstart - prevEnd, mcand);
-                    const int back = min(room, (lane - myHead) + (int)hback);
-                    mstart -= back; mcand -= back;
-                }
-                ENC_LAP(4);
+            // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
+            // are known equal, the head's group measured up to 8 more before the head ----
+            int mstart = myPos, mcand = (int)cand;
+            if (sel) {
+                const int room = min(mstart - prevEnd, mcand);
+                const int back = min(room, delta + (int)((hv >> 8) & 15u));
+                mstart -= back; mcand -= back;
+            }
+            ENC_LAP(4);
+            // ---- park the selected sequences in the queue (stable compaction, one ds_permute per field) ----
+            {
                 const int k = (int)__builtin_popcountll(selm);
                 if (qCnt + k > LZ4_WAVE) flush_queue();
                 const int rk = (int)enc_mbcnt(selm);
@@ -518,15 +519,14 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 const int r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
                 if (lane >= qCnt && lane < qCnt + k) { qPrev = r0; qStart = r1; qLen = r2; qOff = r3; }
                 qCnt += k;
-                anchor = pEnd;
-                missAcc = miss0;
-                ENC_LAP(5);
-            } else if (lowcut < LZ4_WAVE) {
-                missAcc += LZ4_WAVE;               // a window that was probed and selected nothing
             }
+            anchor = pEnd;
+            missAcc = miss0;
+            ENC_LAP(5);
 #ifdef ENC_STATS
             est[6] += 1;
 #endif
+            return nextP;
         };
 #endif  // ENC_NO_PIPE
         while (p < mfl) {
@@ -534,26 +534,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             if (step == 1) {
 #ifndef ENC_NO_PIPE
                 if (pipe_can_issue((int)p)) {
-                    // two windows in flight, in two sets of registers
-                    PipeWin W0, W1;
-                    int np;
-                    stageA(W0, (int)p);
-                    for (;;) {
-                        np = W0.p0 + LZ4_WAVE;
-                        if (anchor > np) np += ((anchor - np) >> 6) << 6;        // windows wholly inside a known match
-                        bool issue = pipe_can_issue(np);
-                        if (issue) stageA(W1, np);
-                        stageC(W0);
-                        if (!issue) break;
-                        np = W1.p0 + LZ4_WAVE;
-                        if (anchor > np) np += ((anchor - np) >> 6) << 6;
-                        issue = pipe_can_issue(np);
-                        if (issue) stageA(W0, np);
-                        stageC(W1);
-                        if (!issue) break;
-                    }
-                    p = max(np, anchor);
-                    pfPos = -1;
+                    int np = (int)p;
+                    do np = group_window(np); while (pipe_can_issue(np));
+                    p = np;
                     continue;
                 }
 #endif
@@ -767,6 +750,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             // ---- forward extension (:1092): first 4 bytes are known equal ----
             int ml = LZ4_MINMATCH;
+#ifndef ENC_NO_PIPE
+            ml += extend_long(mpos + LZ4_MINMATCH, cpos + LZ4_MINMATCH);      // the whole wave, 1 KiB a step
+#else
             {
                 const int maxLen = matchlimit - mpos;
                 while (ml < maxLen) {
@@ -778,6 +764,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     if (run < LZ4_WAVE) break;
                 }
             }
+#endif
             // ---- queue the sequence (written out by flush_queue) ----
             if (qCnt == LZ4_WAVE) flush_queue();
             if (lane == qCnt) { qPrev = anchor; qStart = mpos; qLen = ml; qOff = mpos - cpos; }

@@ -94,7 +94,10 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
 template <bool MOD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, ENC_WAVES_PER_EU))) void k_encode(EncodeArgs a)
 {
-    __shared__ uint16_t table[ENC_TABLE_ENTRIES];           // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU
+#ifndef ENC_LDS_PAD
+#define ENC_LDS_PAD 0
+#endif
+    __shared__ uint16_t table[ENC_TABLE_ENTRIES + ENC_LDS_PAD];   // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU
     const int blk = (int)blockIdx.x;
     const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
     const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
