@@ -51,8 +51,8 @@ static int sim_cur(const uint8_t *src, int n, int accel)
             long step = missAcc >> 6;
             if (step == 1) {
                 int p0 = (int)p;
-                int valid[64], candOk[64], hit[64], head[64], myHead[64]; uint32_t h[64], tg[64], cand[64], ml[64], hback[64];
-                for (int l = 0; l < 64; l++) {
+                int valid[128], candOk[128], hit[128], head[128], myHead[128]; uint32_t h[128], tg[128], cand[128], ml[128], hback[128];
+                for (int l = 0; l < WIN; l++) {
                     int pos = p0 + l; valid[l] = pos < mfl; candOk[l] = hit[l] = head[l] = 0; ml[l] = 0; hback[l] = 0; cand[l] = 0;
                     if (!valid[l]) continue;
                     uint32_t hx = hash16(src + pos); h[l] = hx >> 8; tg[l] = (hx >> (8 - TAGBITS)) & tmask;
@@ -61,7 +61,7 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                     if (!table[h[l]].used && cand[l] == 0 && pos > 0) candOk[l] = (0 == tg[l]);   // zeroed table: tag 0, pos 0
                 }
                 int hd = 0;
-                for (int l = 0; l < 64; l++) {
+                for (int l = 0; l < WIN; l++) {
                     int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
                     head[l] = candOk[l] && !contin;
                     if (head[l]) {
@@ -83,26 +83,26 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                         hit[l] = hit[hd] && m >= 4; ml[l] = hit[l] ? m : 0; hback[l] = hback[hd];
                     }
                 }
-                int any = 0; for (int l = 0; l < 64; l++) any |= hit[l];
+                int any = 0; for (int l = 0; l < WIN; l++) any |= hit[l];
                 g_windows++;
                 if (!any) {
-                    for (int l = 0; l < 64; l++) if (valid[l]) { table[h[l]].pos = (uint16_t)(p0 + l); table[h[l]].tag = tg[l]; table[h[l]].used = 1; }
-                    missAcc += 64; p += 64; continue;
+                    for (int l = 0; l < WIN; l++) if (valid[l]) { table[h[l]].pos = (uint16_t)(p0 + l); table[h[l]].tag = tg[l]; table[h[l]].used = 1; }
+                    missAcc += WIN; p += WIN; continue;
                 }
-                int sel[64]; memset(sel, 0, sizeof(sel));
+                int sel[128]; memset(sel, 0, sizeof(sel));
                 int pEnd = anchor, lastEnd = anchor;
                 {
                     int l = 0;
-                    while (l < 64) {
+                    while (l < WIN) {
                         if (!hit[l]) { l++; continue; }
                         sel[l] = 1; int endk = p0 + l + (int)ml[l]; lastEnd = endk;
-                        int sh = endk - p0; if (sh >= 64) break;
+                        int sh = endk - p0; if (sh >= WIN) break;
                         l = sh;
                     }
                 }
-                int nextP = lastEnd > p0 + 64 ? lastEnd : p0 + 64;
+                int nextP = lastEnd > p0 + WIN ? lastEnd : p0 + WIN;
                 int prevEnd = anchor;
-                for (int l = 0; l < 64; l++) {
+                for (int l = 0; l < WIN; l++) {
                     int pos = p0 + l;
                     // covered: strictly inside a selected match
                     int covered = 0;
@@ -269,6 +269,7 @@ int main(int argc, char **argv)
     TAGBITS = 4; END2 = 1; RUN("cur tag4 +end2", sim_cur(blocks[b], bl, 1)); END2 = 0;
     TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
     TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
+    TAGBITS = 4; WIN = 128; RUN("cur tag4 win128", sim_cur(blocks[b], bl, 1)); WIN = 64;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)
