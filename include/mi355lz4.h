@@ -69,7 +69,24 @@ int mi355lz4_version(void);
 const char *mi355lz4_last_error(void);
 /* Number of usable gfx950 devices (0 when none; never fails). */
 int mi355lz4_device_count(void);
-/* Create an engine bound to HIP device `device` with its own stream. */
+/* Create an engine bound to HIP device `device` with its own stream.
+ *
+ * Threads: an engine is NOT thread-safe -- one engine per thread, or the caller serialises its calls (the
+ * reference's contexts are the same: one per stream, one Haskell thread, Internal/LZ4.hs:105-143).  Different
+ * engines may be used from different threads at the same time.  mi355lz4_last_error is thread-local.
+ *
+ * Streams: every *_device call only ENQUEUES work on the engine's stream (its own, or the one given to
+ * mi355lz4_set_stream) and returns; the exception is a linked decode (linked != 0, or the streams call), which
+ * waits on the host for its first pass before it decides whether a second one is needed.  The scratch memory of a
+ * linked decode belongs to the engine: two linked decodes of ONE engine must be issued on the same stream, or the
+ * caller orders them.  The host-buffer calls (mi355lz4_compress_batch, mi355lz4_decompress_batch, ..._streams)
+ * are synchronous and use, besides the engine's stream, two copy streams and two compute streams created on first
+ * use, plus a small pool of host threads for staging pageable memory (MI355LZ4_COPY_THREADS, default 8); for the
+ * duration of such a call the engine's stream is one of its own.
+ *
+ * Process environment: when this is the first HIP call of the process and GPU_MAX_HW_QUEUES is not set, the first
+ * mi355lz4_create sets it to 8 (the pipelines above need more than HIP's default of four hardware queues to overlap);
+ * MI355LZ4_KEEP_HW_QUEUES=1 turns that off.  Nothing is changed at load time. */
 int mi355lz4_create(mi355lz4_ctx **out, int device);
 void mi355lz4_destroy(mi355lz4_ctx *ctx);
 /* Launch on a caller-owned hipStream_t instead (e.g. torch's current stream). */

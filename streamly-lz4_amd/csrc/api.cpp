@@ -157,6 +157,9 @@ struct mi355lz4_ctx {
     DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
     hipStream_t sIn = nullptr, sOut = nullptr;   // copy streams of the pipelined host-buffer API (created on first use)
     hipStream_t sK[2] = {nullptr, nullptr};   // compute streams: kernels of consecutive groups overlap
+    hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
+    hipStream_t linkStream = nullptr;      // ... and the stream it ran on
+    bool linkBusy = false;
     unsigned long long *stats = nullptr;   // diagnostics: device counters of the lane-parallel decoder (off by default)
 };
 
@@ -273,6 +276,17 @@ extern "C" int mi355lz4_create(mi355lz4_ctx **out, int device)
 {
     if (!out) return fail(MI355LZ4_E_ARG, "mi355lz4_create: null out");
     *out = nullptr;
+    // The host-buffer pipelines use five streams; HIP's default of four hardware queues makes two of them share one.
+    // The variable is read when the HIP runtime initialises, so this only matters when this call is the process's
+    // first HIP call; it never overrides a value the process has set, and MI355LZ4_KEEP_HW_QUEUES=1 leaves the
+    // environment alone altogether (a process that manages its own HIP settings).  Not done at load time any more.
+    {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char *keep = getenv("MI355LZ4_KEEP_HW_QUEUES");
+            if (!(keep && atoi(keep)) && !getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        });
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(MI355LZ4_E_NO_DEVICE, "mi355lz4: no HIP device visible (this engine has no CPU path)");
@@ -299,6 +313,7 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
                       &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf})
         dev_release(*b);
+    if (c->linkEvent) hipEventDestroy(c->linkEvent);
     pin_release(c->pinStat);
     pin_release(c->pinIn);
     pin_release(c->pinOut);
@@ -456,6 +471,20 @@ extern "C" int mi355lz4_compact_device(mi355lz4_ctx *c, const uint8_t *slots, si
     return check_launch("compact launch");
 }
 
+// The scratch of a linked decode (linkBuf, tolPool, tolMeta, ptrBuf) belongs to the engine and its second pass is
+// left in flight on the stream the call was made on.  When the next linked decode comes on ANOTHER stream (the
+// Python binding re-targets the engine to torch's current stream on every call), that stream first waits for the
+// previous use; on the same stream the order is already there.
+static void link_scratch_acquire(mi355lz4_ctx *c)
+{
+    if (c->linkBusy && c->linkEvent && c->linkStream != c->stream) (void)hipStreamWaitEvent(c->stream, c->linkEvent, 0);
+}
+static void link_scratch_release(mi355lz4_ctx *c)
+{
+    if (!c->linkEvent && hipEventCreateWithFlags(&c->linkEvent, hipEventDisableTiming) != hipSuccess) { c->linkEvent = nullptr; return; }
+    if (hipEventRecord(c->linkEvent, c->stream) == hipSuccess) { c->linkStream = c->stream; c->linkBusy = true; }
+}
+
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
@@ -479,6 +508,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
+        link_scratch_acquire(c);
         // the standalone pass counts the blocks that need their dictionary: {count, first, last, -, largest capacity}
         if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 32))) return r;
         a.linkStat = (uint32_t *)c->linkBuf.p;
@@ -496,7 +526,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     launch_longest_stream(a, c->stream);
     HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (stat[0] == 0) return check_launch("decode launch");
+    if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
     const int first = (int)stat[1], last = (int)stat[2];
     if (first < 0 || last >= nBlocks || first > last) return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
     // Lists of deferred matches for up to POOL_BLOCKS dependent blocks at a time (64 KiB each: one byte per output
@@ -548,6 +578,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             launch_linked_resolve(a, c->stream);
         }
     }
+    link_scratch_release(c);
     return check_launch("decode launch");
 }
 
@@ -654,12 +685,8 @@ extern "C" int mi355lz4_event_elapsed_ms(void *start, void *stop, float *ms)
 // ---------------------------------------------------------------------------
 // The pipelined calls keep the caller's stream, two copy streams and two compute streams busy; HIP multiplexes
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialize
-// (measured: compress 33 -> 41 GB/s with 8).  Ask for 8 unless the process says otherwise; it only takes
-// effect if this library is loaded before the HIP runtime initialises.
-__attribute__((constructor)) static void mi355lz4_hw_queues()
-{
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
-}
+// (measured: compress 33 -> 41 GB/s with 8).  mi355lz4_create asks for 8 when it is the first HIP user of the
+// process and nobody has set the variable (see there); nothing is touched at load time.
 
 static bool pipe_trace()
 {

@@ -211,9 +211,17 @@ bool lz4FrameParse(const Array &frame, size_t &at, Lz4FrameIndex &ix)
     return true;
 }
 
+// Blocks are decoded in groups under a byte budget, so that the memory a frame can make this function reserve is
+// bounded by what it actually decodes to plus one budget (a few bytes of input can NAME 4 MiB of output per block:
+// sizing the output by blocks x maximum block size, as round 2 did, let a 100 KB frame ask for tens of GB on the host
+// and on the device).  A block's capacity is also capped by what its compressed bytes can expand to (255 per byte).
+#ifndef LZ4F_GROUP_BUDGET
+#define LZ4F_GROUP_BUDGET ((size_t)256 << 20)
+#endif
 Array lz4FrameDecompress(const Array &frame, Engine &eng)
 {
     Array out;
+    Array scratch;                      // one group's output; grows to the budget at most, reused, never zero-filled twice
     size_t at = 0;
     Lz4FrameIndex ix;
     while (at < frame.size()) {
@@ -224,47 +232,64 @@ Array lz4FrameDecompress(const Array &frame, Engine &eng)
         const std::vector<size_t> &blockAt = ix.blockAt;
         const size_t nBlocks = blockAt.size() - 1;
         const size_t base = out.size();
-        if (nBlocks > 0) {
-            if (nBlocks > 0x7fffffffu) throw Error("lz4FrameDecompress: too many blocks");
-            out.resize(base + nBlocks * bmax);
-            std::vector<int32_t> blen(nBlocks);
+        if (nBlocks > 0x7fffffffu) throw Error("lz4FrameDecompress: too many blocks");
+        std::vector<int32_t> blen;
+        // The engine's linked mode keeps the reference's window: the output of the block before (Internal/LZ4.hs:564,
+        // lz4.c:2347-2355), or the dictionary handed in for the first block of a call.  The frame format's window is
+        // the last 64 KiB of the frame -- the same thing as long as blocks are full.  So a group also ends behind a
+        // block that came out short (a writer that flushed in mid-frame; never liblz4's one-shot LZ4F_compressFrame
+        // or the CLI): the block after it starts the next group and gets the frame's window as that call's dictionary.
+        size_t g0 = 0;
+        while (g0 < nBlocks) {
+            // capacity per block of this group and how many blocks fit the budget
+            size_t cap = 0, g1 = g0;
+            while (g1 < nBlocks) {
+                const size_t clen = blockAt[g1 + 1] - blockAt[g1] - 4;
+                const size_t c1 = std::max(cap, std::min(bmax, clen * 255 + 16));
+                if (g1 > g0 && (g1 - g0 + 1) * c1 > LZ4F_GROUP_BUDGET) break;
+                cap = c1;
+                g1++;
+            }
+            if (ix.hasContentSize) {
+                // a frame that declares its size cannot need more than what is left of it
+                const uint64_t done = out.size() - base;
+                if (done > ix.contentSize) throw Error("lz4FrameDecompress: content size mismatch");
+                cap = (size_t)std::min<uint64_t>(cap, std::max<uint64_t>(ix.contentSize - done, 1));
+            }
+            size_t nb = g1 - g0;
+            if (scratch.size() < nb * cap) scratch.resize(nb * cap);
+            blen.assign(nb, 0);
+            const size_t hist = independent ? 0 : std::min(out.size() - base, (size_t)65536);
+            const uint8_t *dict = hist ? out.data() + out.size() - hist : nullptr;
             size_t got = 0;
-            int nb = 0;
-            int r = mi355lz4_decompress_batch(eng.ctx(), framed.data(), framed.size(), 4, (int)bmax, independent ? 0 : 1,
-                                              nullptr, 0, out.data() + base, nBlocks * bmax, &got, blen.data(), (int)nBlocks, &nb);
-            // The engine's linked mode keeps the reference's window: the output of the block before
-            // (Internal/LZ4.hs:564, lz4.c:2347-2355).  The frame format's window is the last 64 KiB of the frame, which
-            // is the same thing as long as the blocks are full; a writer that flushed short blocks in mid-frame (never
-            // liblz4's one-shot LZ4F_compressFrame or the CLI) needs the blocks behind the first short one decoded
-            // one by one, against the output so far.
-            size_t redo = nBlocks;
-            if (!independent && (r == MI355LZ4_OK || r == MI355LZ4_E_BLOCK)) {
-                for (size_t k = 0; k < nBlocks; k++) {
-                    if (blen[k] < 0) { redo = k; break; }
-                    if ((size_t)blen[k] < std::min(bmax, (size_t)65536) && k + 1 < nBlocks) { redo = k + 1; break; }
-                }
+            int nbOut = 0;
+            int r = mi355lz4_decompress_batch(eng.ctx(), framed.data() + blockAt[g0], blockAt[g1] - blockAt[g0], 4, (int)cap,
+                                              independent ? 0 : 1, dict, (int)hist, scratch.data(), nb * cap, &got, blen.data(),
+                                              (int)nb, &nbOut);
+            if (r != MI355LZ4_OK && r != MI355LZ4_E_BLOCK) throw Error(std::string("lz4FrameDecompress: ") + mi355lz4_last_error());
+            // how many blocks of the group stand: up to the first failure, and (linked) up to and including the first
+            // short block that has a successor in the frame
+            size_t keep = nb;
+            for (size_t k = 0; k < nb; k++) {
+                if (blen[k] < 0) { keep = k; break; }
+                if (!independent && (size_t)blen[k] < std::min(bmax, (size_t)65536) && g0 + k + 1 < nBlocks) { keep = k + 1; break; }
             }
-            if (redo < nBlocks) {
-                size_t w = base;
-                if (r == MI355LZ4_OK) { for (size_t k = 0; k < redo; k++) w += (size_t)blen[k]; }
-                else for (size_t k = 0; k < redo; k++) {                        // not packed yet: block k sits at k * bmax
-                    memmove(out.data() + w, out.data() + base + k * bmax, (size_t)blen[k]);
-                    w += (size_t)blen[k];
-                }
-                for (size_t k = redo; k < nBlocks; k++) {
-                    const size_t hist = std::min(w - base, (size_t)65536);
-                    Array one(bmax);
-                    int32_t bl = 0;
-                    r = mi355lz4_decompress_batch(eng.ctx(), framed.data() + blockAt[k], blockAt[k + 1] - blockAt[k], 4, (int)bmax, 1,
-                                                  hist ? out.data() + w - hist : nullptr, (int)hist, one.data(), bmax, &got, &bl, 1, &nb);
-                    if (r != MI355LZ4_OK) break;
-                    memcpy(out.data() + w, one.data(), got);
-                    w += got;
-                }
-                got = w - base;
+            if (keep == 0) {
+                // the group's first block had the whole window and still fails: the frame is damaged
+                                throw Error(std::string("lz4FrameDecompress: ") + (r == MI355LZ4_OK ? "block decode failed" : mi355lz4_last_error()));
             }
-            if (r != MI355LZ4_OK) throw Error(std::string("lz4FrameDecompress: ") + mi355lz4_last_error());
-            out.resize(base + got);
+            if (keep < nb || r != MI355LZ4_OK) {
+                // decode exactly the blocks that stand (what a failed call leaves in the output buffer is not part of the
+                // C ABI's contract)
+                nb = keep;
+                g1 = g0 + keep;
+                r = mi355lz4_decompress_batch(eng.ctx(), framed.data() + blockAt[g0], blockAt[g1] - blockAt[g0], 4, (int)cap,
+                                              independent ? 0 : 1, dict, (int)hist, scratch.data(), nb * cap, &got, blen.data(),
+                                              (int)nb, &nbOut);
+                if (r != MI355LZ4_OK) throw Error(std::string("lz4FrameDecompress: ") + mi355lz4_last_error());
+            }
+            out.insert(out.end(), scratch.data(), scratch.data() + got);
+            g0 = g1;
         }
         if (ix.hasContentSize && (uint64_t)(out.size() - base) != ix.contentSize) throw Error("lz4FrameDecompress: content size mismatch");
         if (ix.hasContentChecksum && ix.contentChecksum != xxh32(out.data() + base, out.size() - base, 0))

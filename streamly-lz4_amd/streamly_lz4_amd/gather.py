@@ -45,38 +45,100 @@ def interleave(local, local_off, rank, n_ranks, global_buf, global_off, engine=N
         global_buf[d:d + n] = local[lo[j]:lo[j + 1]]
 
 
-def gather_ordered(local, local_sizes, root=0, engine=None, group=None):
+STAGE_BYTES = 256 << 20        # a peer's stream crosses the link in pieces of at most this many bytes (whole blocks)
+
+
+def _pieces(sizes64, limit):
+    """Cut blocks 0..n into runs of consecutive blocks of at most `limit` bytes (at least one block each).
+    Every rank computes the same cut from the all-gathered sizes.  Returns [(j0, j1, byte0, byte1)]."""
+    off = [0]
+    for v in sizes64.tolist():
+        off.append(off[-1] + int(v))
+    out, j0 = [], 0
+    n = len(off) - 1
+    while j0 < n:
+        j1 = j0 + 1
+        while j1 < n and off[j1 + 1] - off[j0] <= limit:
+            j1 += 1
+        out.append((j0, j1, off[j0], off[j1]))
+        j0 = j1
+    return out
+
+
+def _order_engine_after_torch(engine, tensor):
+    """The interleave kernel runs on the ENGINE's stream; the receive it reads was ordered against torch's current
+    stream by req.wait().  They are the same stream while the engine follows torch (the default); an engine pinned
+    to a stream of its own (Engine.use_stream) has to wait for torch's stream first."""
+    if engine is not None and tensor.is_cuda and getattr(engine, "_pinned", False):
+        torch.cuda.current_stream(tensor.device).synchronize()
+
+
+def gather_ordered(local, local_sizes, root=0, engine=None, group=None, stage_bytes=None):
     """Gather every rank's dense local stream (uint8 tensor `local`, per-block byte counts
     `local_sizes` int32) into one in-order stream on `root`.  Returns (stream, global_off) on the
-    root and (None, global_off) elsewhere."""
+    root and (None, global_off) elsewhere.
+
+    A peer's stream crosses its link in pieces of whole blocks (<= stage_bytes, default 256 MiB); the root keeps two
+    staging buffers per peer and places a piece (HIP interleave kernel) while the next one is in flight, so its
+    staging memory is 2 x stage_bytes per peer whatever the streams' sizes (round 2 staged every peer in full)."""
     rank = dist.get_rank(group)
     G = dist.get_world_size(group)
     dev = local.device
+    limit = int(stage_bytes or STAGE_BYTES)
     sizes, goff = global_layout(local_sizes, group)
-    loff = torch.zeros(local_sizes.numel() + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(local_sizes.to(torch.int64), 0, out=loff[1:])
+    sizes64 = [x.to(torch.int64).cpu() for x in sizes]
     if rank != root:
-        n = int(loff[-1].item())
-        dist.isend(local[:n].contiguous(), dst=root, group=group).wait()
+        # (the piece number is the message tag: gloo does not match equal tags in order; RCCL ignores tags and is FIFO)
+        reqs = [dist.isend(local[b0:b1].contiguous(), dst=root, group=group, tag=k)
+                for k, (_j0, _j1, b0, b1) in enumerate(pc for pc in _pieces(sizes64[rank], limit) if pc[3] > pc[2])]
+        for r in reqs:
+            r.wait()
         return None, goff
     total = int(goff[-1].item())
     out = torch.empty(total, dtype=torch.uint8, device=dev)
-    pending = []
+    loff = torch.zeros(local_sizes.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(local_sizes.to(torch.int64), 0, out=loff[1:])
+    peers = []
     for g in range(G):
         if g == root:
             continue
-        n = int(sizes[g].to(torch.int64).sum().item())
-        stage = torch.empty(n, dtype=torch.uint8, device=dev)
-        pending.append((g, stage, dist.irecv(stage, src=g, group=group)))
-    # The engine launches on torch's current stream (Engine._follow_torch), the stream req.wait() orders the
-    # receive against: no host synchronisation is needed between a receive and its interleave.
-    interleave(local, loff, root, G, out, goff, engine)                  # overlaps with the receives
-    for g, stage, req in pending:                                         # each peer is placed as soon as it has arrived
-        req.wait()
         poff = torch.zeros(sizes[g].numel() + 1, dtype=torch.int64, device=dev)
         torch.cumsum(sizes[g].to(torch.int64), 0, out=poff[1:])
-        interleave(stage, poff, g, G, out, goff, engine)
-    del pending
+        pcs = [pc for pc in _pieces(sizes64[g], limit) if pc[3] > pc[2]]
+        cap = max([pc[3] - pc[2] for pc in pcs], default=0)
+        peers.append({"g": g, "poff": poff, "pieces": pcs, "next": 0, "inflight": [],
+                      "stages": [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(min(2, len(pcs)))]})
+
+    def post(p):
+        while p["next"] < len(p["pieces"]) and len(p["inflight"]) < len(p["stages"]):
+            k = p["next"]
+            j0, j1, b0, b1 = p["pieces"][k]
+            stage = p["stages"][k % len(p["stages"])][: b1 - b0]
+            p["inflight"].append((k, stage, dist.irecv(stage, src=p["g"], group=group, tag=k)))
+            p["next"] += 1
+
+    for p in peers:
+        post(p)
+    interleave(local, loff, root, G, out, goff, engine)                  # overlaps with the receives
+    busy = True
+    while busy:
+        busy = False
+        for p in peers:                                                   # round-robin over the peers: one piece each
+            if not p["inflight"]:
+                continue
+            busy = True
+            k, stage, req = p["inflight"].pop(0)
+            req.wait()
+            _order_engine_after_torch(engine, stage)
+            j0, j1, b0, b1 = p["pieces"][k]
+            interleave(stage, p["poff"][j0:j1 + 1] - b0, p["g"], G, out, goff[j0 * G:], engine)
+            if stage.is_cuda and len(p["pieces"]) > len(p["stages"]):
+                # the staging buffer is reused by a later receive: the kernel that reads it must be done first
+                if engine is not None:
+                    engine.synchronize()
+            post(p)
     if out.is_cuda:
-        torch.cuda.current_stream().synchronize()
+        if engine is not None:
+            engine.synchronize()
+        torch.cuda.current_stream(dev).synchronize()
     return out, goff

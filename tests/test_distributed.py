@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n_global, seed, q):
+def _worker(rank, world, port, n_global, seed, q, stage_bytes=None):
     for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_global, seed, q):
         mine = [blocks[k] for k in range(rank, n_global, world)]                       # block k -> rank k % G
         local = torch.from_numpy(np.concatenate(mine))
         lsz = torch.tensor([len(b) for b in mine], dtype=torch.int32)
-        out, goff = gather_ordered(local, lsz, root=0)
+        out, goff = gather_ordered(local, lsz, root=0, stage_bytes=stage_bytes)
         if rank == 0:
             want = np.concatenate(blocks)
             ok = out is not None and np.array_equal(out.numpy(), want) and \
@@ -39,12 +39,14 @@ def _worker(rank, world, port, n_global, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_global", [2, 10, 64])
-def test_gather_ordered_world2(n_global):
+@pytest.mark.parametrize("n_global,stage_bytes", [(2, None), (10, None), (64, None), (64, 300), (66, 1), (200, 1000)])
+def test_gather_ordered_world2(n_global, stage_bytes):
+    """stage_bytes: the peer's stream crosses in pieces of whole blocks (two staging buffers on the root); 1 = a
+    piece per block."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + n_global
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, 7, q)) for r in range(2)]
+    port = 29600 + n_global + (stage_bytes or 0) % 97
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, 7, q, stage_bytes)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

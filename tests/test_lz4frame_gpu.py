@@ -165,3 +165,37 @@ def test_corruption_is_detected(eng):
     f[5000] ^= 0xFF
     with pytest.raises(slz.LZ4Error):
         slz.lz4FrameDecompress(bytes(f), eng)
+
+
+def _tiny_block_frame(n_blocks, bd=0x70):
+    """A frame that NAMES 4 MiB per block and holds one literal per block: [size 2][token 0x10][byte]."""
+    import streamly_lz4_amd as slz
+    desc = bytes([0x60, bd])                                    # version 01, independent blocks; BD: 4 MiB
+    hc = (slz.xxh32(desc) >> 8) & 0xFF
+    body = b"".join(struct.pack("<I", 2) + bytes([0x10, 65 + (k % 26)]) for k in range(n_blocks))
+    return struct.pack("<I", 0x184D2204) + desc + bytes([hc]) + body + struct.pack("<I", 0)
+
+
+def test_crafted_frame_cannot_reserve_more_than_it_decodes(eng):
+    """Round-2 advisor finding: the output used to be sized as blocks x maximum block size before anything was
+    decoded -- 20 000 two-byte blocks with BD = 4 MiB asked for 80 GB on the host and on the device.  Blocks are
+    now decoded in groups under a byte budget, each block capped by what its bytes can expand to."""
+    import resource
+    import streamly_lz4_amd as slz
+    n = 20000
+    frame = _tiny_block_frame(n)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    out = slz.lz4FrameDecompress(frame, eng)
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert out == bytes(65 + (k % 26) for k in range(n))
+    assert (after - before) < (1 << 20), "peak RSS grew by more than 1 GiB (KiB units): %d" % (after - before)
+
+
+@needs_lz4f
+def test_linked_frame_longer_than_one_group(eng):
+    """A linked frame whose blocks do not fit one group (4 MiB blocks, 256 MiB budget): the window crosses the seam
+    as the next call's dictionary."""
+    import streamly_lz4_amd as slz
+    data = _text(70 * (4 << 20) // 16, 21) * 16                 # 280 MiB of text with long-range repeats
+    frame = lz4f.compress_frame(L, data, block_id=7, linked=True, content_checksum=True)
+    assert slz.lz4FrameDecompress(frame, eng) == data
