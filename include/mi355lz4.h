@@ -217,6 +217,33 @@ int mi355lz4_decompress_streams(mi355lz4_ctx *ctx, const uint8_t *framedIn, size
                                 int fixedUncomp, const int32_t *streamFirst, int nStreams, uint8_t *out,
                                 size_t cap, size_t *outLen, int32_t *blockLen, int maxBlocks, int *nBlocks);
 
+/* ---- one linked stream over several GPUs ----------
+ * A linked stream does not shard by round-robin: block k's dictionary is the
+ * output of block k-1 (cbits/lz4.c:2347-2355).  It shards by CONTIGUOUS RANGES:
+ * engine r decodes blocks [b_r, b_r+1) and needs one thing from engine r-1, the
+ * output of block b_r - 1 (the seam: at most 64 KiB of it are ever read).
+ *
+ * _begin issues everything that does not READ that output: the standalone pass,
+ * the tolerant re-decode of the dependent blocks, source pointers and pointer
+ * jumping over the range (where a byte comes from depends on tokens only).
+ * _end issues the rest: the bytes are fetched from their roots, the first of
+ * which lie in the seam, and the results are set.  Between the two calls the
+ * caller places the seam at out + outOff[-1] (its size in result[-1]) in the
+ * engine's stream order.  lookBack = 1 says outOff[-1] / result[-1] exist (the
+ * arrays handed in point at their second element); lookBack = 0: the range
+ * starts the stream.  Otherwise the arguments are those of
+ * mi355lz4_decompress_batch_device with linked != 0, and so are the results.
+ * Spread over G engines the serial part of a stream is G fetches, not G ranges
+ * (streamly_lz4_amd/linked_shard.py drives it over torch.distributed).
+ * A range whose dependent blocks do not fit one pointer segment
+ * (MI355LZ4_LINKED_PTR_BLOCKS, default 4096 blocks of 64 KiB) is correct but
+ * leaves all its work to _end. */
+int mi355lz4_decompress_linked_begin(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
+                                     const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                                     uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
+                                     int32_t *result, int lookBack);
+int mi355lz4_decompress_linked_end(mi355lz4_ctx *ctx);
+
 /* ---- synthetic inputs (bench / test support; SURVEY.md 8d generators) ---
  * kind: 0 = xorshift64* random, 1 = lzsynth(litMax, offMax), 2 = text-like.
  * Block i of the batch is seeded by (firstBlock + i * blockStep); it is written

@@ -157,6 +157,12 @@ struct mi355lz4_ctx {
     DevBuf pinMeta;         // pinned: per-group sizes coming back from the device
     hipStream_t sIn = nullptr, sOut = nullptr;   // copy streams of the pipelined host-buffer API (created on first use)
     hipStream_t sK[2] = {nullptr, nullptr};   // compute streams: kernels of consecutive groups overlap
+    // a linked decode whose data half is still to be issued (mi355lz4_decompress_linked_begin / _end)
+    struct LinkedPlan {
+        bool active = false, split = false;
+        DecodeArgs a;
+        int first = 0, last = -1, pool = 0, seg = 0;
+    } plan;
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
     bool linkBusy = false;
@@ -485,12 +491,39 @@ static void link_scratch_release(mi355lz4_ctx *c)
     if (hipEventRecord(c->linkEvent, c->stream) == hipSuccess) { c->linkStream = c->stream; c->linkBusy = true; }
 }
 
+// The data half of a linked decode (see LinkedPlan): everything that reads output bytes.
+static int linked_finish(mi355lz4_ctx *c)
+{
+    if (!c->plan.active) return MI355LZ4_OK;
+    c->plan.active = false;
+    DecodeArgs a = c->plan.a;
+    const int first = c->plan.first, last = c->plan.last, pool = c->plan.pool, seg = c->plan.seg;
+    if (c->plan.split) {
+        launch_linked_resolve_b(a, c->stream);
+    } else {
+        for (int p0 = first; p0 <= last; p0 += pool) {
+            const int p1 = (last + 1 - p0 < pool) ? last + 1 : p0 + pool;
+            a.segFirst = p0; a.segEnd = p1;
+            launch_linked_tolerant(a, c->stream);
+            for (int b = p0; b < p1; b += seg) {
+                a.segFirst = b;
+                a.segEnd = (p1 - b < seg) ? p1 : b + seg;
+                launch_linked_resolve(a, c->stream);
+            }
+        }
+    }
+    link_scratch_release(c);
+    return check_launch("decode launch");
+}
+
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
-                         uint32_t dict0Len, const int32_t *streamFirst = nullptr, int nStreams = 0, int lookBack = 0)
+                         uint32_t dict0Len, const int32_t *streamFirst = nullptr, int nStreams = 0, int lookBack = 0,
+                         bool splitOk = false, bool deferEnd = false)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (c->plan.active) return fail(MI355LZ4_E_ARG, "a linked decode begun with mi355lz4_decompress_linked_begin is still open");
     if (nBlocks < 0 || (headerKind != 4 && headerKind != 8) || fixedUncomp < 0)
         return fail(MI355LZ4_E_ARG, "decompress_batch_device: bad arguments");
     if (nBlocks == 0) return MI355LZ4_OK;
@@ -568,17 +601,18 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         }
     }
     (void)hipGetLastError();          // scratch that could not be had is not an error: the serial walk needs none
-    for (int p0 = first; p0 <= last; p0 += pool) {
-        const int p1 = (last + 1 - p0 < pool) ? last + 1 : p0 + pool;
-        a.segFirst = p0; a.segEnd = p1;
+    c->plan.active = true;
+    c->plan.a = a; c->plan.first = first; c->plan.last = last; c->plan.pool = pool; c->plan.seg = seg;
+    // When one segment covers every dependent block, the half of the second pass that reads no output byte can be
+    // issued now: lists, pointers and the first jump pass depend on the tokens only.
+    c->plan.split = splitOk && a.ptr && span <= seg && span <= pool;
+    if (c->plan.split) {
+        a.segFirst = first; a.segEnd = last + 1;
         launch_linked_tolerant(a, c->stream);
-        for (int b = p0; b < p1; b += seg) {
-            a.segFirst = b;
-            a.segEnd = (p1 - b < seg) ? p1 : b + seg;
-            launch_linked_resolve(a, c->stream);
-        }
+        launch_linked_resolve_a(a, c->stream);
+        c->plan.a = a;
     }
-    link_scratch_release(c);
+    if (!deferEnd) return linked_finish(c);
     return check_launch("decode launch");
 }
 
@@ -589,6 +623,23 @@ extern "C" int mi355lz4_decompress_batch_device(mi355lz4_ctx *c, const uint8_t *
 {
     return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, linked, out, outOff,
                          outCap, result, nullptr, 0);
+}
+
+extern "C" int mi355lz4_decompress_linked_begin(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,
+                                               const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,
+                                               uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
+                                               int32_t *result, int lookBack)
+{
+    if (lookBack < 0 || lookBack > 1) return fail(MI355LZ4_E_ARG, "decompress_linked_begin: lookBack must be 0 or 1");
+    return decode_device(c, framed, framedLen, blockOff, nBlocks, headerKind, fixedUncomp, 1, out, outOff, outCap, result,
+                         nullptr, 0, nullptr, 0, lookBack, true, true);
+}
+
+extern "C" int mi355lz4_decompress_linked_end(mi355lz4_ctx *c)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    return linked_finish(c);
 }
 
 extern "C" int mi355lz4_decompress_streams_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,

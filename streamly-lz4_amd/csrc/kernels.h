@@ -69,6 +69,8 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
 #define PAR_STATS_COUNT 32
 void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s);   // both cover blocks [a.segFirst, a.segEnd)
 void launch_linked_resolve(const DecodeArgs &a, hipStream_t s);
+void launch_linked_resolve_a(const DecodeArgs &a, hipStream_t s);   // pointers only (no output byte is read)
+void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fetch, finish, fallbacks
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();

@@ -961,7 +961,11 @@ void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_decode_tolerant, dim3((unsigned)n), dim3(64), 0, s, a);
 }
 
-void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
+// The pointer pass in two halves.  The first touches pointers only -- where every byte of the segment comes from
+// is known from the tokens (lists) alone; the second reads DATA: the roots, the first of which lie in the block in
+// front of the segment.  mi355lz4_decompress_linked_begin / _end run them apart so that the output of that block
+// (the seam of a stream that is spread over several GPUs) may arrive in between.
+void launch_linked_resolve_a(const DecodeArgs &a, hipStream_t s)
 {
     const int n = a.segEnd - a.segFirst;
     if (n <= 0) return;
@@ -969,8 +973,17 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
         // (the stream flags follow the control block: a stream turned down in one segment gets its chance in the next)
         hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
         hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
-        const unsigned items = ptr_grid(n), few = std::min(items, 4096u);
+        const unsigned items = ptr_grid(n);
         hipLaunchKernelGGL(k_ptr_jump, dim3(items), dim3(256), 0, s, a, 0, items);
+    }
+}
+
+void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
+    if (a.tolPool && a.ptr && a.ptrCtl && a.ptrBad) {
+        const unsigned items = ptr_grid(n), few = std::min(items, 4096u);
         hipLaunchKernelGGL(k_ptr_fetch<true>, dim3(items), dim3(256), 0, s, a, items);
         // (what follows usually finds nothing to do: small grids that stride over the items)
         for (int pass = 1; pass < PTR_MAX_PASSES; pass++)
@@ -984,4 +997,10 @@ void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
                            dim3(RPL_THREADS), 0, s, a);
     else if (a.nStreams > 0)
         hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);
+}
+
+void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)
+{
+    launch_linked_resolve_a(a, s);
+    launch_linked_resolve_b(a, s);
 }

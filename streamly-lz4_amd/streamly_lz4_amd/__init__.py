@@ -88,6 +88,9 @@ def _load():
         vp, vp, vp, vp)
     sig("mi355lz4_decompress_streams_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp,
         C.c_int, vp, vp, vp, vp)
+    sig("mi355lz4_decompress_linked_begin", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+        C.c_int)
+    sig("mi355lz4_decompress_linked_end", C.c_int, vp)
     sig("mi355lz4_index_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp)
     sig("mi355lz4_compress_batch", C.c_int, vp, C.POINTER(_u8p), _i32p, C.c_int, C.c_int, C.c_int, _u8p,
         C.c_size_t, C.POINTER(C.c_size_t), _i32p, _i32p)
@@ -143,7 +146,8 @@ DECLARED_SYMBOLS = [
     "mi355lz4_version", "mi355lz4_last_error", "mi355lz4_device_count", "mi355lz4_create", "mi355lz4_destroy",
     "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder", "mi355lz4_set_linked_compress",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
-    "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
+    "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_decompress_linked_begin",
+    "mi355lz4_decompress_linked_end", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
     "mi355lz4_decompress_batch", "mi355lz4_decompress_streams", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
     "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
     "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
@@ -344,6 +348,23 @@ class Engine:
             self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind),
             int(fixed_uncomp), _dptr(stream_first), int(n_streams), _dptr(out), _dptr(out_off), _dptr(out_cap),
             _dptr(result)), "decompress_streams_device")
+
+    def decompress_linked_begin(self, framed, framed_len, block_off, n_blocks, out, out_off, result, look_back,
+                                header_kind=8, fixed_uncomp=0):
+        """First half of a linked decode of a contiguous RANGE of one stream (include/mi355lz4.h): everything that does
+        not read the output of the block in front of the range.  With look_back = 1, out_off (int64, n_blocks + 2) and
+        result (int32, n_blocks + 1) carry one leading entry for that block: where its output will be and its size."""
+        self._follow_torch()
+        lb = 1 if look_back else 0
+        _check(lib.mi355lz4_decompress_linked_begin(
+            self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind), int(fixed_uncomp),
+            _dptr(out), C.c_void_p(out_off.data_ptr() + 8 * lb), None, C.c_void_p(result.data_ptr() + 4 * lb), lb),
+            "decompress_linked_begin")
+
+    def decompress_linked_end(self):
+        """Second half: fetch from the roots (the first of which lie in the look-back block's output), results."""
+        self._follow_torch()
+        _check(lib.mi355lz4_decompress_linked_end(self.ctx), "decompress_linked_end")
 
     def index_device(self, framed, framed_len, block_off, n_blocks, out_off, header_kind=8, fixed_uncomp=0):
         self._follow_torch()
