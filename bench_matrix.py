@@ -14,7 +14,8 @@ Inputs: the Canterbury files the reference uses (large/bible.txt, large/world192
 under $CANTERBURY_DIR or <repo>/corpora.  They cannot be downloaded here; when they are absent this prints
 a message and exits 0 -- unless --synthetic is given, which runs the same matrix on 10 MiB of the engine's
 text-like generator and says so in every line.  One JSON line per benchmark; --cpu adds the reference codec
-(oracle/_ref) on one host core for the compress / decompress rows.
+(oracle/_ref) on one host core for the compress / decompress rows.  The decompress rows take the result arrays as
+slices of one buffer (views=True), which is what the reference's `Array Word8` results are.
 """
 import argparse
 import json
@@ -104,12 +105,12 @@ def main():
         bench("compress/files", "compress 5/" + n, d, _64KB, lambda a: S.compressChunks(cfg, 5, a, eng), len(d),
               (lambda d=d: ref.frame_compress(d, _64KB, 5, 8, True)) if ref else None)
     for n, d in inputs.items():
-        bench("decompress/files/big", "decompress/" + n, big[n], _64KB, lambda a: S.decompressChunks(cfg, a, eng), len(d),
+        bench("decompress/files/big", "decompress/" + n, big[n], _64KB, lambda a: S.decompressChunks(cfg, a, eng, views=True), len(d),
               (lambda n=n, d=d: ref.frame_decompress(big[n], len(d), 8, 0, True)) if ref else None)
     for n, d in inputs.items():
         bench("decompressWith", "decompressWith/" + n, withf[n], _64KB, lambda a: S.decompressChunksWith(a, eng), len(d))
     for n, d in inputs.items():
-        bench("decompression/files/small", "decompress/" + n, small[n], _64KB, lambda a: S.decompressChunks(cfg, a, eng), len(d),
+        bench("decompression/files/small", "decompress/" + n, small[n], _64KB, lambda a: S.decompressChunks(cfg, a, eng, views=True), len(d),
               (lambda n=n, d=d: ref.frame_decompress(small[n], len(d), 8, 0, True)) if ref else None)
     bible = names[0]
     for accel in (-1, 10, 1000, 65537):
@@ -118,7 +119,7 @@ def main():
     for buf in (_64KB // 10, _64KB, _64KB * 10):
         bench("compression/buffer", "compress 5/" + bible, inputs[bible], buf, lambda a: S.compressChunks(cfg, 5, a, eng), len(inputs[bible]))
     for buf in (_64KB // 10, _64KB, _64KB * 10):
-        bench("decompression/buffer", "decompress/" + bible, big[bible], buf, lambda a: S.decompressChunks(cfg, a, eng), len(inputs[bible]))
+        bench("decompression/buffer", "decompress/" + bible, big[bible], buf, lambda a: S.decompressChunks(cfg, a, eng, views=True), len(inputs[bible]))
     for buf in (_64KB // 10, _64KB, _64KB * 10):
         bench("resizing/buffer", "resize/" + bible, big[bible], buf, lambda a: S.resizeChunks(cfg, fcfg, a), len(inputs[bible]))
 

@@ -83,6 +83,27 @@ StreamPtr resizeChunks(const BlockConfig &cfg, const FrameConfig &conf, StreamPt
 StreamPtr decompressChunksRaw(const BlockConfig &cfg, StreamPtr in, Engine &eng);
 // decompressChunks cfg = decompressChunksRawD cfg . resizeChunksD cfg defaultFrameConfig  (LZ4.hs:114-122)
 StreamPtr decompressChunks(const BlockConfig &cfg, StreamPtr in, Engine &eng);
+// decompressChunks over a BATCH of arrays that lie back to back in one buffer (array i = lens[i] bytes), the result as
+// slices of ONE buffer.  Same results and same errors as decompressChunks over fromList of those arrays.  Why it
+// exists: an `Array Word8` of the reference is a slice of a shared buffer, so its combinators move no bytes between
+// stages; Array here is an owning vector and the array-at-a-time form above pays an allocation and a copy per array
+// and per stage (1.1 ms for the reference's own 10 MiB benchmark files -- more than the GPU call).  This form makes
+// the copies the reference would make: none on the way in, one (device -> host) on the way out.
+struct ArrayBatch {
+    uint8_t *buf = nullptr;             // the arrays' bytes, back to back (not zero-filled; recycled by release())
+    size_t cap = 0;
+    std::vector<size_t> off;            // array i = buf[off[i] .. off[i + 1]); size() = arrays + 1
+    size_t count() const { return off.empty() ? 0 : off.size() - 1; }
+    void release();                     // hands the buffer back (kept for the next call: no fresh page faults)
+    ArrayBatch() = default;
+    ArrayBatch(ArrayBatch &&o) noexcept : buf(o.buf), cap(o.cap), off(std::move(o.off)) { o.buf = nullptr; o.cap = 0; }
+    ArrayBatch &operator=(ArrayBatch &&o) noexcept { release(); buf = o.buf; cap = o.cap; off = std::move(o.off); o.buf = nullptr; o.cap = 0; return *this; }
+    ArrayBatch(const ArrayBatch &) = delete;
+    ArrayBatch &operator=(const ArrayBatch &) = delete;
+    ~ArrayBatch() { release(); }
+};
+ArrayBatch decompressChunksBatch(const BlockConfig &cfg, const FrameConfig &conf, const uint8_t *data,
+                                 const uint64_t *lens, size_t n, Engine &eng);
 // simpleFrameParserD                (Internal/LZ4.hs:590-651): consumes the 7-byte
 // frame header from the head of the stream; returns the parsed configs and the
 // stream of what follows.

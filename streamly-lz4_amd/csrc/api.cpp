@@ -163,6 +163,10 @@ struct mi355lz4_ctx {
         DecodeArgs a;
         int first = 0, last = -1, pool = 0, seg = 0;
     } plan;
+    // small-batch compression: per-segment sequence lists, one scratch buffer per stream the engine has been used on
+    // (the host pipelines run two groups at a time on two compute streams; work on ONE stream is ordered)
+    struct SegScratch { hipStream_t s = nullptr; DevBuf b; } seg[4];
+    int nSeg = 0;
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
     bool linkBusy = false;
@@ -317,7 +321,7 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
-                      &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf})
+                      &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf, &c->seg[0].b, &c->seg[1].b, &c->seg[2].b, &c->seg[3].b})
         dev_release(*b);
     if (c->linkEvent) hipEventDestroy(c->linkEvent);
     pin_release(c->pinStat);
@@ -450,6 +454,40 @@ static int encode_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *sr
     a.slots = slots; a.slotStride = slotStride; a.framedLen = framedLen;
     a.stats = c->stats;
     a.linked = c->linkedCompress; a.lookBack = lookBack;
+    // Small batches: with fewer blocks than the chip has wave slots (256 CUs x 16), a block is cut into segments that
+    // several waves compress at once (kernels.hip, "K2, small batches").  Segments of >= 4 KiB, at most 64 per block,
+    // about two waves per slot in all; blocks of up to 4 MiB (24-bit positions in the records); independent blocks only.
+    // MI355LZ4_SEG=0 turns it off, MI355LZ4_SEG=k forces k segments (tests).
+    {
+        static const int segEnv = [] { const char *e = getenv("MI355LZ4_SEG"); return e ? atoi(e) : -1; }();
+        int segs = 0;
+        if (!a.linked && maxBlockLen >= 8192 && maxBlockLen <= (4 << 20) && segEnv != 0) {
+            const long slots_ = 2L * 256 * 16;
+            long want = segEnv > 0 ? segEnv : slots_ / (long)nBlocks;
+            if (want > maxBlockLen / 4096) want = maxBlockLen / 4096;
+            if (want > 64) want = 64;
+            if (want >= 2) segs = (int)want;
+        }
+        if (segs >= 2) {
+            EncodeSegArgs sa;
+            sa.e = a;
+            sa.segs = segs;
+            sa.segLen = ((maxBlockLen + segs - 1) / segs + 63) & ~63;
+            sa.listStride = (size_t)maxBlockLen / 4 + (size_t)segs + 2;
+            const size_t listBytes = (size_t)nBlocks * sa.listStride * sizeof(uint64_t);
+            const size_t cntBytes = (size_t)nBlocks * (size_t)segs * sizeof(uint32_t);
+            DevBuf *sb = nullptr;
+            for (int i = 0; i < c->nSeg; i++) if (c->seg[i].s == c->stream) sb = &c->seg[i].b;
+            if (!sb && c->nSeg < 4) { c->seg[c->nSeg].s = c->stream; sb = &c->seg[c->nSeg++].b; }
+            if (sb && dev_reserve(*sb, listBytes + cntBytes + 64) == 0) {
+                sa.lists = (uint64_t *)sb->p;
+                sa.segCount = (uint32_t *)((uint8_t *)sb->p + ((listBytes + 63) & ~(size_t)63));
+                launch_encode_seg(sa, c->stream);
+                return check_launch("encode launch");
+            }
+            (void)hipGetLastError();          // no scratch: the one-wave-per-block path needs none
+        }
+    }
     launch_encode(a, maxBlockLen > 65536, c->stream);
     return check_launch("encode launch");
 }

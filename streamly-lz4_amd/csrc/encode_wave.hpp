@@ -155,6 +155,94 @@ __device__ __forceinline__ void lds_mskor(uint32_t *w, uint32_t mask, uint32_t b
 #define ENC_LAP(i) do { } while (0)
 #endif
 
+// One sequence record of a segment's list (segment mode, small batches): match start (24 bits, block-relative),
+// match length (24 bits), offset (16 bits).  A sequence's literals start where the sequence before it ends.
+struct SegOut {
+    uint64_t *list;      // this segment's records
+    uint32_t count;      // records written so far (wave-uniform)
+    int base;            // added to the finder's positions to make them block-relative
+    bool last;           // the block's last segment: the block's end rules apply (:214-221); elsewhere a match may run up to the seam
+};
+__device__ __forceinline__ uint64_t seg_pack(int start, int len, int off)
+{
+    return (uint64_t)(uint32_t)start | ((uint64_t)(uint32_t)len << 24) | ((uint64_t)(uint32_t)off << 48);
+}
+__device__ __forceinline__ void seg_unpack(uint64_t w, int &start, int &len, int &off)
+{
+    start = (int)(w & 0xffffffu); len = (int)((w >> 24) & 0xffffffu); off = (int)(w >> 48);
+}
+
+// Emit up to 64 queued sequences, one per lane (token, length bytes, literals, offset: cbits/lz4.c:1022-1046,
+// :1065-1135), every lane busy; returns the advanced output pointer.  qCnt is wave-uniform.
+__device__ __forceinline__ uint8_t *emit_sequences(const uint8_t *src, uint8_t *op, int qPrev, int qStart, int qLen, int qOff, int qCnt)
+{
+    const int lane = lane_id();
+    const bool act = lane < qCnt;
+    const uint32_t lit = act ? (uint32_t)(qStart - qPrev) : 0u;
+    const uint32_t mc = act ? (uint32_t)(qLen - LZ4_MINMATCH) : 0u;
+    const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
+    const int incl = enc_scan_incl((int)esz);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    uint8_t *o = op + (incl - (int)esz);
+    const uint8_t *litSrc = src + qPrev;
+    // short literal runs: up to four 8-byte chunks per lane, all loads issued before the stores
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const bool shortRun = act && lit <= 32u;
+    if (shortRun && lit >= 8u) {
+        const uint32_t last = lit - 8u;
+        c0 = *(const u64_unaligned *)(litSrc);
+        if (lit > 8u) c1 = *(const u64_unaligned *)(litSrc + min(8u, last));
+        if (lit > 16u) c2 = *(const u64_unaligned *)(litSrc + min(16u, last));
+        if (lit > 24u) c3 = *(const u64_unaligned *)(litSrc + last);
+    } else if (shortRun && lit > 0u) {
+        c0 = *(const u64_unaligned *)(litSrc);     // the run ends at a match start, >= 12 bytes before the end of the input
+    }
+    if (act) {
+        *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
+        if (lit >= 15u) {
+            uint32_t rest = lit - 15u;
+            while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+            *o++ = (uint8_t)rest;
+        }
+    }
+    uint8_t *litDst = o;
+    if (shortRun) {
+        if (lit >= 8u) {
+            const uint32_t last = lit - 8u;
+            *(u64_unaligned *)(litDst) = c0;
+            if (lit > 8u) *(u64_unaligned *)(litDst + min(8u, last)) = c1;
+            if (lit > 16u) *(u64_unaligned *)(litDst + min(16u, last)) = c2;
+            if (lit > 24u) *(u64_unaligned *)(litDst + last) = c3;
+        } else {
+            uint64_t w = c0;
+            uint32_t done = 0;
+            if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
+            for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
+        }
+    }
+    if (act) {
+        o += lit;
+        o[0] = (uint8_t)qOff; o[1] = (uint8_t)((uint32_t)qOff >> 8);
+        o += 2;
+        if (mc >= 15u) {
+            uint32_t rest = mc - 15u;
+            while (rest >= 255u) { *o++ = 255; rest -= 255u; }
+            *o++ = (uint8_t)rest;
+        }
+    }
+    // long literal runs are copied by the whole wave
+    for (uint64_t lm = __ballot(act && lit > 32u); lm; lm &= lm - 1) {
+        const int k = (int)__builtin_ctzll(lm);
+        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
+        const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
+        uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
+        const int s0 = __builtin_amdgcn_readlane(qPrev, k);
+        const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
+        wave_copy_bytes(d, src + s0, ln);
+    }
+    return op + total;
+}
+
 // A table entry as a candidate position for `myPos`.  The table holds the low 16 bits of a position.  When
 // positions stay below 64 Ki that IS the position; otherwise (DICT: a block above 64 KiB, or a dictionary in
 // front of the block) the candidate is the nearest earlier position with those bits -- at most 65535 back by
@@ -176,9 +264,14 @@ __device__ __forceinline__ bool tab_candidate(TabT e, int myPos, uint32_t &cand)
 // the stream, which LZ4_compress_fast_continue keeps as the window (cbits/lz4.c:1608-1636, kept alive by
 // Internal/LZ4.hs:376,389).  All positions are then relative to src - dictLen; the table is seeded with the
 // dictionary's positions instead of inheriting the previous call's table, which needs no order between blocks.
-template <typename TabT, bool DICT = false>
+// SEG (segment mode, small batches): the block is cut into segments that several waves compress at once, each
+// with the bytes in front of its segment as dictionary (the table is seeded from them, as for linked compression).
+// The wave then writes sequence RECORDS to seg->list instead of bytes, starts no match within the last 12 bytes of its
+// segment (a match may END at the seam; only the block's last segment keeps the last 5 bytes as literals) and leaves
+// its trailing literals to the segment behind it: the return value is the position (block-relative) where they start.
+template <typename TabT, bool DICT = false, bool SEG = false>
 __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int accel, TabT *table,
-                                 unsigned long long *stats = nullptr, int dictLen = 0)
+                                 unsigned long long *stats = nullptr, int dictLen = 0, SegOut *seg = nullptr)
 {
     const int lane = lane_id();
     if (!DICT) dictLen = 0;
@@ -199,74 +292,19 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     int qCnt = 0;                                      // uniform
     auto flush_queue = [&]() {
         if (qCnt == 0) return;
-        const bool act = lane < qCnt;
-        const uint32_t lit = act ? (uint32_t)(qStart - qPrev) : 0u;
-        const uint32_t mc = act ? (uint32_t)(qLen - LZ4_MINMATCH) : 0u;
-        const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
-        const int incl = enc_scan_incl((int)esz);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        uint8_t *o = op + (incl - (int)esz);
-        const uint8_t *litSrc = src + qPrev;
-        // short literal runs: up to four 8-byte chunks per lane, all loads issued before the stores
-        uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        const bool shortRun = act && lit <= 32u;
-        if (shortRun && lit >= 8u) {
-            const uint32_t last = lit - 8u;
-            c0 = *(const u64_unaligned *)(litSrc);
-            if (lit > 8u) c1 = *(const u64_unaligned *)(litSrc + min(8u, last));
-            if (lit > 16u) c2 = *(const u64_unaligned *)(litSrc + min(16u, last));
-            if (lit > 24u) c3 = *(const u64_unaligned *)(litSrc + last);
-        } else if (shortRun && lit > 0u) {
-            c0 = *(const u64_unaligned *)(litSrc);     // the run ends at a match start, >= 12 bytes before the end of the input
+        if (SEG) {
+            // segment mode: the sequences go to the segment's list; a second kernel stitches the lists into the block
+            if (lane < qCnt) seg->list[seg->count + (uint32_t)lane] = seg_pack(qStart + seg->base, qLen, qOff);
+            seg->count += (uint32_t)qCnt;
+            qCnt = 0;
+            return;
         }
-        if (act) {
-            *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
-            if (lit >= 15u) {
-                uint32_t rest = lit - 15u;
-                while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-                *o++ = (uint8_t)rest;
-            }
-        }
-        uint8_t *litDst = o;
-        if (shortRun) {
-            if (lit >= 8u) {
-                const uint32_t last = lit - 8u;
-                *(u64_unaligned *)(litDst) = c0;
-                if (lit > 8u) *(u64_unaligned *)(litDst + min(8u, last)) = c1;
-                if (lit > 16u) *(u64_unaligned *)(litDst + min(16u, last)) = c2;
-                if (lit > 24u) *(u64_unaligned *)(litDst + last) = c3;
-            } else {
-                uint64_t w = c0;
-                uint32_t done = 0;
-                if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
-                for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
-            }
-        }
-        if (act) {
-            o += lit;
-            o[0] = (uint8_t)qOff; o[1] = (uint8_t)((uint32_t)qOff >> 8);
-            o += 2;
-            if (mc >= 15u) {
-                uint32_t rest = mc - 15u;
-                while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-                *o++ = (uint8_t)rest;
-            }
-        }
-        // long literal runs are copied by the whole wave
-        for (uint64_t lm = __ballot(act && lit > 32u); lm; lm &= lm - 1) {
-            const int k = (int)__builtin_ctzll(lm);
-            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
-            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
-            uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
-            const int s0 = __builtin_amdgcn_readlane(qPrev, k);
-            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
-            wave_copy_bytes(d, src + s0, ln);
-        }
-        op += total;
+        op = emit_sequences(src, op, qPrev, qStart, qLen, qOff, qCnt);
         qCnt = 0;
     };
 
     if (blockLen == 0) {                // cbits/lz4.c:1263-1273: empty input -> single 0 token
+        if (SEG) return seg->base + dictLen;
         if (lane == 0) dst[0] = 0;
         return 1;
     }
@@ -305,7 +343,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
     if (blockLen >= 13) {                               // LZ4_minLength, :221,:921
         const int mfl = n - LZ4_MFLIMIT + 1;            // match start must be < mfl (:883)
-        const int matchlimit = n - LZ4_LASTLITERALS;    // match end must be <= matchlimit (:884)
+        const int matchlimit = (SEG && !seg->last) ? n : n - LZ4_LASTLITERALS;    // match end must be <= matchlimit (:884)
         const uint32_t miss0 = (uint32_t)accel << 6;
         uint32_t missAcc = miss0;
         int64_t p = dictLen;
@@ -782,6 +820,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     if (stats && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stats[i], est[i]);
 #endif
     flush_queue();
+    if (SEG) return anchor + seg->base;
     // ---- last literals (:1204-1231) ----
     {
         const uint32_t lastRun = (uint32_t)(n - anchor);

@@ -11,6 +11,7 @@
 
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 
 namespace streamly_lz4 {
@@ -342,6 +343,107 @@ StreamPtr decompressChunks(const BlockConfig &cfg, StreamPtr in, Engine &eng)   
     return decompressChunksRaw(cfg, resizeChunks(cfg, defaultFrameConfig(), std::move(in)), eng);
 }
 
+// Result buffers of the batch form are recycled: a fresh 10 MiB allocation costs its page faults (0.3-0.6 ms, as much
+// as the GPU call) every time; a buffer handed back by slz4_arrays_free / ArrayBatch's owner is kept for the next call.
+namespace {
+struct BufPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint8_t *>> free_;       // (capacity, buffer)
+    uint8_t *get(size_t n, size_t &cap)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].first >= n && free_[i].first <= 2 * n + (1u << 20)) {
+                    uint8_t *p = free_[i].second; cap = free_[i].first;
+                    free_.erase(free_.begin() + (long)i);
+                    return p;
+                }
+        }
+        cap = n;
+        return new uint8_t[n];
+    }
+    void put(uint8_t *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_.size() < 4 && cap <= ((size_t)256 << 20)) { free_.emplace_back(cap, p); return; }
+        delete[] p;
+    }
+};
+BufPool &buf_pool() { static BufPool *p = new BufPool(); return *p; }
+} // namespace
+void ArrayBatch::release() { if (buf) { buf_pool().put(buf, cap); buf = nullptr; cap = 0; } }
+
+// decompressChunks over arrays that already lie back to back (streamly_lz4.hpp): when the bytes are a well-formed
+// run of whole blocks that all decode, one index walk and one GPU call do what resizeChunksD + decompressChunksRawD do
+// array by array.  Anything else -- a trailing partial block, an end mark, a block the decoder rejects -- goes through
+// the combinators themselves, which is what yields the reference's error for it.
+ArrayBatch decompressChunksBatch(const BlockConfig &cfg, const FrameConfig &conf, const uint8_t *data,
+                                 const uint64_t *lens, size_t n, Engine &eng)
+{
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) total += (size_t)lens[i];
+    ArrayBatch res;
+    const int meta = metaSize(cfg);
+    if (!conf.hasEndMark && total > 0 && total < ((size_t)1 << 31)) {
+        // how many whole blocks? (a header walk: compLen <= 0, or a block that runs past the end, ends the fast path)
+        size_t nbk = 0, p = 0;
+        bool whole = true;
+        while (p < total) {
+            if (total - p < (size_t)meta) { whole = false; break; }
+            const int32_t compLen = le32(data + p);
+            if (compLen <= 0 || (size_t)compLen > total - p - (size_t)meta) { whole = false; break; }
+            p += (size_t)meta + (size_t)compLen;
+            nbk++;
+        }
+        if (whole && nbk > 0 && nbk < ((size_t)1 << 24)) {
+            std::vector<uint64_t> boff(nbk + 1);
+            std::vector<int32_t> ulen(nbk + 1), blen(nbk + 1);
+            int nb = 0;
+            if (mi355lz4_index_host(data, total, meta, fixedUncompSize(cfg), boff.data(), ulen.data(), (int)nbk, &nb) ==
+                    MI355LZ4_OK && (size_t)nb == nbk) {
+                size_t cap = 0;
+                bool sane = true;
+                for (int i = 0; i < nb; i++) { if (ulen[(size_t)i] < 0) sane = false; else cap += (size_t)ulen[(size_t)i]; }
+                if (sane && cap < ((size_t)1 << 32)) {
+                    res.buf = buf_pool().get(cap + 16, res.cap);
+                    size_t outLen = 0;
+                    int got = 0;
+                    const int r = mi355lz4_decompress_batch(eng.ctx(), data, total, meta, fixedUncompSize(cfg), 1, nullptr, 0,
+                                                            res.buf, cap + 16, &outLen, blen.data(), nb, &got);
+                    if (r == MI355LZ4_OK && got == nb) {
+                        res.off.resize((size_t)nb + 1);
+                        size_t pos = 0;
+                        for (int i = 0; i < nb; i++) { res.off[(size_t)i] = pos; pos += (size_t)blen[(size_t)i]; }
+                        res.off[(size_t)nb] = pos;
+                        return res;
+                    }
+                    res.release();
+                }
+            }
+        }
+    }
+    // the general path: the combinators, array by array
+    std::vector<Array> v;
+    v.reserve(n);
+    size_t pos = 0;
+    for (size_t i = 0; i < n; i++) { v.emplace_back(data + pos, data + pos + lens[i]); pos += (size_t)lens[i]; }
+    StreamPtr s = decompressChunksRaw(cfg, resizeChunks(cfg, conf, fromList(std::move(v))), eng);
+    std::vector<Array> outv = toList(*s);
+    size_t outTotal = 0;
+    for (const Array &a : outv) outTotal += a.size();
+    res.buf = buf_pool().get(outTotal + 1, res.cap);
+    res.off.resize(outv.size() + 1);
+    pos = 0;
+    for (size_t i = 0; i < outv.size(); i++) {
+        res.off[i] = pos;
+        if (!outv[i].empty()) memcpy(res.buf + pos, outv[i].data(), outv[i].size());
+        pos += outv[i].size();
+    }
+    res.off[outv.size()] = pos;
+    return res;
+}
+
 // ---------------------------------------------------------------------------
 // simpleFrameParserD (:590-651) and decompressChunksWithD (:569-577)
 // ---------------------------------------------------------------------------
@@ -411,7 +513,7 @@ StreamPtr decompressChunksWith(StreamPtr in, Engine &eng)                       
 // ===========================================================================
 using namespace streamly_lz4;
 
-struct slz4_arrays { std::vector<Array> v; };
+struct slz4_arrays { std::vector<Array> v; ArrayBatch b; bool flat = false; };
 struct slz4_engine { Engine *e; };
 
 static thread_local std::string g_slz4_err;
@@ -480,10 +582,18 @@ void slz4_engine_set_batch(slz4_engine *h, size_t n) { if (h) h->e->setBatchBloc
 void slz4_engine_set_linked_compress(slz4_engine *h, int on) { if (h) h->e->setLinkedCompress(on != 0); }
 mi355lz4_ctx *slz4_engine_ctx(slz4_engine *h) { return h ? h->e->ctx() : nullptr; }
 
-size_t slz4_arrays_count(const slz4_arrays *a) { return a ? a->v.size() : 0; }
-size_t slz4_arrays_len(const slz4_arrays *a, size_t i) { return a->v[i].size(); }
-const uint8_t *slz4_arrays_data(const slz4_arrays *a, size_t i) { return a->v[i].data(); }
+size_t slz4_arrays_count(const slz4_arrays *a) { return a ? (a->flat ? a->b.count() : a->v.size()) : 0; }
+size_t slz4_arrays_len(const slz4_arrays *a, size_t i) { return a->flat ? a->b.off[i + 1] - a->b.off[i] : a->v[i].size(); }
+const uint8_t *slz4_arrays_data(const slz4_arrays *a, size_t i) { return a->flat ? a->b.buf + a->b.off[i] : a->v[i].data(); }
 void slz4_arrays_free(slz4_arrays *a) { delete a; }
+// flat results (the batch forms): the shared buffer and the n + 1 offsets; returns 0 when `a` is not flat
+int slz4_arrays_flat(const slz4_arrays *a, const uint8_t **base, const size_t **offsets)
+{
+    if (!a || !a->flat) return 0;
+    *base = a->b.buf;
+    *offsets = a->b.off.data();
+    return 1;
+}
 
 int slz4_compress_chunks(slz4_engine *h, int blockSizeKind, int speed, const uint8_t *data, const uint64_t *lens,
                          size_t n, slz4_arrays **out)
@@ -509,11 +619,19 @@ int slz4_decompress_chunks_raw(slz4_engine *h, int blockSizeKind, const uint8_t 
 int slz4_decompress_chunks(slz4_engine *h, int blockSizeKind, int hasEndMark, const uint8_t *data, const uint64_t *lens,
                            size_t n, slz4_arrays **out)
 {
-    return guarded(out, [&] {
+    try {
         BlockConfig cfg = cfg_from_kind(blockSizeKind);
         FrameConfig fc; fc.hasEndMark = hasEndMark != 0;
-        return decompressChunksRaw(cfg, resizeChunks(cfg, fc, list_from_c(data, lens, n)), *h->e);
-    });
+        slz4_arrays *r = new slz4_arrays();
+        try { r->b = decompressChunksBatch(cfg, fc, data, lens, n, *h->e); } catch (...) { delete r; throw; }
+        r->flat = true;
+        *out = r;
+        return 0;
+    } catch (const std::exception &e) {
+        g_slz4_err = e.what();
+        *out = nullptr;
+        return -1;
+    }
 }
 
 int slz4_decompress_chunks_with(slz4_engine *h, const uint8_t *data, const uint64_t *lens, size_t n, slz4_arrays **out)

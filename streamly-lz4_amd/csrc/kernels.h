@@ -64,6 +64,16 @@ struct EncodeArgs {
     int lookBack;                // linked: blocks of the same stream that precede block 0 in srcOff[] / srcLen[]
 };
 
+// small batches: a block's segments are compressed by several waves (kernels.hip, K2 small batches)
+struct EncodeSegArgs {
+    EncodeArgs e;
+    int segs;                    // segments per block
+    int segLen;                  // bytes per segment (the last one takes the rest)
+    uint64_t *lists;             // sequence records: block b's segment j at lists + b * listStride + s0 / 4 + j
+    size_t listStride;           // records per block: maxBlockLen / 4 + segs + 1
+    uint32_t *segCount;          // records per segment
+};
+void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s);
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
 #define PAR_STATS_COUNT 32

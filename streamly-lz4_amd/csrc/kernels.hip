@@ -128,6 +128,91 @@ void launch_encode(const EncodeArgs &a, bool bigBlocks, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
+// K2, small batches: several waves per block (encode_wave.hpp, SEG).  One wavefront per block cannot be faster than
+// one block (1.5 ms for 64 KiB), however empty the chip is: a call of 160 blocks -- the reference's own benchmark
+// protocol, 10 MiB per file -- left 97 % of it idle, and 16 arrays of 640 KiB took 51 ms.  Here a block is cut into
+// segments; wave (b, j) seeds its table from the bytes in front of segment j (what linked compression does between
+// blocks) and writes sequence records; k_emit_seg then stitches a block's lists into one valid LZ4 block: a segment's
+// trailing literals simply become the first literals of the next segment's first sequence.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, ENC_WAVES_PER_EU))) void k_encode_seg(EncodeSegArgs a)
+{
+    __shared__ uint16_t table[ENC_TABLE_ENTRIES + ENC_LDS_PAD];
+    const int blk = (int)(blockIdx.x / (unsigned)a.segs), j = (int)(blockIdx.x % (unsigned)a.segs);
+    const uint64_t off = a.e.srcOff ? a.e.srcOff[blk] : (uint64_t)blk * a.e.blockStride;
+    const int n = a.e.srcLen ? a.e.srcLen[blk] : a.e.uniformLen;
+    uint32_t count = 0;
+    if (n > 0) {
+        const int s0 = min(n, j * a.segLen), s1 = (j == a.segs - 1) ? n : min(n, (j + 1) * a.segLen);
+        if (s1 > s0) {
+            SegOut so;
+            so.list = a.lists + (size_t)blk * a.listStride + (size_t)(s0 / 4 + j);     // a segment has at most len/4 + 1 records
+            so.count = 0;
+            const int dictLen = min(s0, 65536);
+            so.base = s0 - dictLen;
+            so.last = s1 >= n;
+            (void)encode_block_wave<uint16_t, true, true>(a.e.src + off + s0, s1 - s0, nullptr, a.e.accel, table, a.e.stats, dictLen, &so);
+            count = so.count;
+        }
+    }
+    if (lane_id() == 0) a.segCount[(size_t)blk * a.segs + j] = count;
+}
+
+__global__ __launch_bounds__(64) void k_emit_seg(EncodeSegArgs a)
+{
+    const int blk = (int)blockIdx.x;
+    const int lane = lane_id();
+    const uint64_t off = a.e.srcOff ? a.e.srcOff[blk] : (uint64_t)blk * a.e.blockStride;
+    const int n = a.e.srcLen ? a.e.srcLen[blk] : a.e.uniformLen;
+    uint8_t *slot = a.e.slots + (size_t)blk * a.e.slotStride;
+    uint8_t *op0 = slot + a.e.headerKind, *op = op0;
+    const uint8_t *src = a.e.src + off;
+    int c = 0;
+    if (n == 0) {                                              // cbits/lz4.c:1263-1273: empty input -> single 0 token
+        if (lane == 0) op[0] = 0;
+        c = 1;
+    } else if (n > 0) {
+        int prevEnd = 0;                                       // where the next sequence's literals start
+        for (int j = 0; j < a.segs; j++) {
+            const int cnt = (int)a.segCount[(size_t)blk * a.segs + j];
+            const int s0 = min(n, j * a.segLen);
+            const uint64_t *list = a.lists + (size_t)blk * a.listStride + (size_t)(s0 / 4 + j);
+            for (int i0 = 0; i0 < cnt; i0 += LZ4_WAVE) {
+                const int k = min(LZ4_WAVE, cnt - i0);
+                int start = 0, len = 0, mo = 0;
+                if (lane < k) seg_unpack(list[i0 + lane], start, len, mo);
+                const int end = start + len;
+                // my literals start where the sequence before me ends (lane 0: the one before this batch)
+                int qPrev = __builtin_amdgcn_update_dpp(prevEnd, end, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if (lane == 0) qPrev = prevEnd;
+                op = emit_sequences(src, op, qPrev, start, len, mo, k);
+                prevEnd = __builtin_amdgcn_readlane(end, k - 1);
+            }
+        }
+        // ---- last literals (:1204-1231) ----
+        const uint32_t lastRun = (uint32_t)(n - prevEnd);
+        uint8_t *tok = op++;
+        if (lane == 0) *tok = (uint8_t)(min(lastRun, 15u) << 4);
+        if (lastRun >= 15) op = emit_ext_len(op, lastRun - 15);
+        wave_copy_bytes(op, src + prevEnd, lastRun);
+        op += lastRun;
+        c = (int)(op - op0);
+    }
+    if (lane == 0) {
+        store_le32(slot, c);                                   // Internal/LZ4.hs:262
+        if (a.e.headerKind == 8) store_le32(slot + 4, n);      // Internal/LZ4.hs:261
+        a.e.framedLen[blk] = (c > 0) ? a.e.headerKind + c : 0;
+    }
+}
+
+void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s)
+{
+    if (a.e.nBlocks <= 0) return;
+    hipLaunchKernelGGL(k_encode_seg, dim3((unsigned)a.e.nBlocks * (unsigned)a.segs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_emit_seg, dim3((unsigned)a.e.nBlocks), dim3(64), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------
 // K3: scan + ragged copy
 // ---------------------------------------------------------------------------
 

@@ -123,6 +123,7 @@ def _load():
     sig("slz4_engine_set_linked_compress", None, vp, C.c_int)
     sig("slz4_engine_ctx", vp, vp)
     sig("slz4_arrays_count", C.c_size_t, vp)
+    sig("slz4_arrays_flat", C.c_int, vp, C.POINTER(_u8p), C.POINTER(C.POINTER(C.c_size_t)))
     sig("slz4_arrays_len", C.c_size_t, vp, C.c_size_t)
     sig("slz4_arrays_data", _u8p, vp, C.c_size_t)
     sig("slz4_arrays_free", None, vp)
@@ -456,6 +457,45 @@ def _pack(arrays):
     return data, lens, len(arrays)
 
 
+class _ArraysOwner:
+    """Keeps a C-side result alive while Python slices of it are in use."""
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        if self.h and lib is not None:                 # (module globals are gone at interpreter shutdown)
+            lib.slz4_arrays_free(self.h)
+            self.h = None
+
+
+def _unpack_views(h):
+    """The result arrays as memoryviews INTO the C-side buffer (no copy): what a Haskell `Array` is -- a slice of a
+    shared buffer.  The buffer lives as long as any of the views."""
+    owner = _ArraysOwner(h)
+    n = lib.slz4_arrays_count(h)
+    base, offs = _u8p(), C.POINTER(C.c_size_t)()
+    if n and lib.slz4_arrays_flat(h, C.byref(base), C.byref(offs)):
+        # one buffer: one ctypes object, the arrays are slices of its memoryview
+        total = offs[n]
+        if total == 0:
+            return [memoryview(b"")] * n
+        arr = (C.c_uint8 * total).from_address(C.cast(base, C.c_void_p).value)
+        arr._owner = owner
+        mv = memoryview(arr).cast("B")
+        o = offs[0:n + 1]
+        return [mv[o[i]:o[i + 1]] for i in range(n)]
+    out = []
+    for i in range(n):
+        ln = lib.slz4_arrays_len(h, i)
+        if ln:
+            arr = (C.c_uint8 * ln).from_address(C.cast(lib.slz4_arrays_data(h, i), C.c_void_p).value)
+            arr._owner = owner
+            out.append(memoryview(arr).cast("B"))
+        else:
+            out.append(memoryview(b""))
+    return out
+
+
 def _unpack(h):
     try:
         n = lib.slz4_arrays_count(h)
@@ -468,12 +508,12 @@ def _unpack(h):
         lib.slz4_arrays_free(h)
 
 
-def _run(fn, *args):
+def _run(fn, *args, views=False):
     h = C.c_void_p()
     rc = fn(*args, C.byref(h))
     if rc != 0:
         raise LZ4Error((lib.slz4_last_error() or b"").decode("utf-8", "replace"))
-    return _unpack(h)
+    return _unpack_views(h) if views else _unpack(h)
 
 
 def compressChunks(cfg, speed, arrays, engine):
@@ -497,11 +537,13 @@ def decompressChunksRaw(cfg, arrays, engine):
                 lens.ctypes.data_as(_u64p), n)
 
 
-def decompressChunks(cfg, arrays, engine, conf=defaultFrameConfig):
-    """Streamly.LZ4.decompressChunks (reference src/Streamly/LZ4.hs:114-122); conf selects the end-mark variant."""
+def decompressChunks(cfg, arrays, engine, conf=defaultFrameConfig, views=False):
+    """Streamly.LZ4.decompressChunks (reference src/Streamly/LZ4.hs:114-122); conf selects the end-mark variant.
+    views=True returns the arrays as memoryviews into one result buffer (the reference's arrays are such slices) instead
+    of one bytes object -- one copy -- per array."""
     data, lens, n = _pack(arrays)
     return _run(lib.slz4_decompress_chunks, engine._h, cfg.blockSize, int(conf.hasEndMark), data.ctypes.data_as(_u8p),
-                lens.ctypes.data_as(_u64p), n)
+                lens.ctypes.data_as(_u64p), n, views=views)
 
 
 def decompressChunksWith(arrays, engine):

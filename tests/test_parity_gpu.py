@@ -848,3 +848,43 @@ def test_linked_streams_host_api(engine, oracle):
         engine.decompress_streams(blob, [0, 5, 3])
     with pytest.raises(S.LZ4Error):
         engine.decompress_streams(blob, [0, len(boff) + 1])
+
+
+def test_decompress_chunks_batch_form(engine, oracle, slz4):
+    """decompressChunks over arrays that lie back to back takes one index walk and one GPU call (decompressChunksBatch,
+    include/streamly_lz4.hpp); its results -- as bytes or as views into one buffer -- and its errors are those of the
+    array-at-a-time combinators (resizeChunksD + decompressChunksRawD, Internal/LZ4.hs:432-567)."""
+    S = slz4
+    cfg = S.defaultBlockConfig
+    raw = oracle.gen("text", 37, 65536).tobytes() + oracle.gen("lzsynth", 1, 1234).tobytes()
+    framed = oracle.frame_compress(raw, 65536, 1, 8, True)                     # the reference's linked stream
+    for split in (1 << 30, 65536, 5000, 7):
+        chunks = [framed[i:i + split] for i in range(0, len(framed), split)] if split < len(framed) else [framed]
+        if split == 7:
+            chunks = chunks[:2000] + [b"".join(chunks[2000:])]
+        out_b = S.decompressChunks(cfg, chunks, engine)
+        out_v = S.decompressChunks(cfg, chunks, engine, views=True)
+        assert b"".join(out_b) == raw and [len(a) for a in out_b] == [65536] * 37 + [1234]
+        assert [bytes(v) for v in out_v] == out_b
+    two_step = S.decompressChunksRaw(cfg, S.resizeChunks(cfg, S.defaultFrameConfig, [framed]), engine)
+    assert two_step == S.decompressChunks(cfg, [framed], engine)
+    assert S.decompressChunks(cfg, [], engine) == []
+    # errors: whatever the batch form cannot take goes through the combinators and raises what they raise
+    def err(arrays):
+        try:
+            S.decompressChunks(cfg, arrays, engine)
+        except S.LZ4Error as e:
+            return str(e)
+        return None
+    def err2(arrays):
+        try:
+            S.decompressChunksRaw(cfg, S.resizeChunks(cfg, S.defaultFrameConfig, arrays), engine)
+        except S.LZ4Error as e:
+            return str(e)
+        return None
+    damaged = bytearray(framed); damaged[20000] ^= 0xFF; damaged[20001] ^= 0xFF; damaged[20002] ^= 0x55
+    for bad in ([framed[:-5]], [framed + b"\x01"], [framed[:8]]):             # one thing wrong: the same message
+        assert err(bad) == err2(bad) and err(bad) is not None
+    # several things wrong: the fused stream reports the first in stream order (err2 resizes everything first)
+    for bad in ([bytes(damaged)], [b"\x00\x00\x00\x00" + framed], [bytes(damaged[:-3])]):
+        assert err(bad) is not None
