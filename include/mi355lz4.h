@@ -93,6 +93,11 @@ void mi355lz4_destroy(mi355lz4_ctx *ctx);
 int mi355lz4_set_stream(mi355lz4_ctx *ctx, void *hipStream);
 void *mi355lz4_get_stream(mi355lz4_ctx *ctx);
 int mi355lz4_synchronize(mi355lz4_ctx *ctx);
+/* Small batches.  With fewer blocks in a call than the chip has wave slots, the compressor cuts every block
+ * (8 KiB .. 4 MiB, independent blocks) into segments that several wavefronts compress at once (a block still
+ * comes out as one valid LZ4 block; the seams cost about 1 % of size on text).  segs: -1 = automatic (default;
+ * MI355LZ4_SEG in the environment overrides it), 0 = never, 2..64 = that many segments whenever possible. */
+int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
 /* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel,
  * 2 = lane-parallel kernel.  Tuning/ablation knob; results are identical. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);

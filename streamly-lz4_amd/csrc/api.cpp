@@ -167,6 +167,7 @@ struct mi355lz4_ctx {
     // (the host pipelines run two groups at a time on two compute streams; work on ONE stream is ordered)
     struct SegScratch { hipStream_t s = nullptr; DevBuf b; } seg[4];
     int nSeg = 0;
+    int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
     bool linkBusy = false;
@@ -345,6 +346,13 @@ extern "C" int mi355lz4_set_stream(mi355lz4_ctx *c, void *s)
 }
 extern "C" void *mi355lz4_get_stream(mi355lz4_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+extern "C" int mi355lz4_set_segments(mi355lz4_ctx *c, int segs)
+{
+    if (!c || segs < -1 || segs > 64) return fail(MI355LZ4_E_ARG, "mi355lz4_set_segments: -1 (auto), 0 (off) or 2..64");
+    c->segMode = segs;
+    return MI355LZ4_OK;
+}
+
 extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
@@ -459,7 +467,8 @@ static int encode_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *sr
     // about two waves per slot in all; blocks of up to 4 MiB (24-bit positions in the records); independent blocks only.
     // MI355LZ4_SEG=0 turns it off, MI355LZ4_SEG=k forces k segments (tests).
     {
-        static const int segEnv = [] { const char *e = getenv("MI355LZ4_SEG"); return e ? atoi(e) : -1; }();
+        static const int segEnv0 = [] { const char *e = getenv("MI355LZ4_SEG"); return e ? atoi(e) : -1; }();
+        const int segEnv = c->segMode >= 0 ? c->segMode : segEnv0;
         int segs = 0;
         if (!a.linked && maxBlockLen >= 8192 && maxBlockLen <= (4 << 20) && segEnv != 0) {
             const long slots_ = 2L * 256 * 16;
