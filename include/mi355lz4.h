@@ -93,6 +93,15 @@ void mi355lz4_destroy(mi355lz4_ctx *ctx);
 int mi355lz4_set_stream(mi355lz4_ctx *ctx, void *hipStream);
 void *mi355lz4_get_stream(mi355lz4_ctx *ctx);
 int mi355lz4_synchronize(mi355lz4_ctx *ctx);
+/* Linked decodes without a host wait.  mi355lz4_decompress_batch_device(linked != 0) normally waits on the host for
+ * its first pass, to learn whether any block needs its dictionary and which ones (a stream of independent blocks pays
+ * that wait and nothing else).  With maxDecodedBlockSize > 0 (an upper bound of any block's decoded size, e.g. 65536)
+ * the call only enqueues: the second pass is issued over all blocks of the call and its kernels return at once when
+ * the first pass found nothing to do (about a dozen empty launches per 4096 blocks).  The call can then be captured in
+ * a graph and no longer serialises a caller's pipeline; it costs more than the wait on big batches of independent
+ * blocks (measured in DESIGN.md), which is why it is opt-in.  0 restores the default.  The streams call
+ * (mi355lz4_decompress_streams_device) always waits. */
+int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
 /* Small batches.  With fewer blocks in a call than the chip has wave slots, the compressor cuts every block
  * (8 KiB .. 4 MiB, independent blocks) into segments that several wavefronts compress at once (a block still
  * comes out as one valid LZ4 block; the seams cost about 1 % of size on text).  segs: -1 = automatic (default;

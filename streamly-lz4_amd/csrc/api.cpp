@@ -167,6 +167,7 @@ struct mi355lz4_ctx {
     // (the host pipelines run two groups at a time on two compute streams; work on ONE stream is ordered)
     struct SegScratch { hipStream_t s = nullptr; DevBuf b; } seg[4];
     int nSeg = 0;
+    int linkedAsyncCap = 0;                // > 0: linked device decodes do not wait on the host (mi355lz4_set_linked_async)
     int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
@@ -345,6 +346,13 @@ extern "C" int mi355lz4_set_stream(mi355lz4_ctx *c, void *s)
     return MI355LZ4_OK;
 }
 extern "C" void *mi355lz4_get_stream(mi355lz4_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int mi355lz4_set_linked_async(mi355lz4_ctx *c, int maxDecodedBlockSize)
+{
+    if (!c || maxDecodedBlockSize < 0) return fail(MI355LZ4_E_ARG, "mi355lz4_set_linked_async: bad arguments");
+    c->linkedAsyncCap = maxDecodedBlockSize;
+    return MI355LZ4_OK;
+}
 
 extern "C" int mi355lz4_set_segments(mi355lz4_ctx *c, int segs)
 {
@@ -585,6 +593,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr;
+    a.asyncGate = 0;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -603,9 +612,22 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // Linked streams.  Whether there is a second pass at all, and over which blocks, is decided here: the
     // call waits for the standalone pass (a stream of independent blocks pays this wait and nothing else).
     uint32_t *stat = (uint32_t *)c->pinStat.p;
-    launch_longest_stream(a, c->stream);
-    HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // Asynchronous form (mi355lz4_set_linked_async; MI355LZ4_LINKED_ASYNC=<largest decoded block size> for the tests):
+    // no wait on the host.  The second pass is enqueued over ALL blocks, its kernels return at once when the first
+    // pass counted no dependent block; what the wait would have told -- the range of dependent blocks and the largest
+    // block -- is replaced by the whole call and the caller's bound.  One stream only (the streams call keeps the wait:
+    // its choice between walk and pointer pass needs the counts).
+    int asyncCap = c->linkedAsyncCap;
+    if (const char *e = getenv("MI355LZ4_LINKED_ASYNC")) asyncCap = atoi(e);
+    if (asyncCap > 0 && !streamFirst) {
+        a.asyncGate = 1;
+        stat[0] = (uint32_t)nBlocks; stat[1] = 0; stat[2] = (uint32_t)(nBlocks - 1); stat[3] = (uint32_t)nBlocks;
+        stat[4] = (uint32_t)asyncCap;
+    } else {
+        launch_longest_stream(a, c->stream);
+        HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
     const int first = (int)stat[1], last = (int)stat[2];
     if (first < 0 || last >= nBlocks || first > last) return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);

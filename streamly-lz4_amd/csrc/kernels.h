@@ -45,6 +45,7 @@ struct DecodeArgs {
     uint64_t ptrCap;              // ... capacity in pointers
     void *ptrCtl;                 // PtrCtl
     uint32_t *ptrBad;             // per stream (one entry without streamFirst): left to the serial walk
+    int asyncGate;                // second-pass kernels return at once when linkStat[0] == 0 (asynchronous linked decode)
 };
 
 struct EncodeArgs {

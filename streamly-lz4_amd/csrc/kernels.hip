@@ -434,6 +434,7 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
 // streams run side by side.  
 __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     __shared__ ParLds lds;
     const int sIdx = (int)blockIdx.x;
     if (a.ptrBad && !a.ptrBad[sIdx]) return;                        // the data-parallel pass has done this stream
@@ -480,6 +481,7 @@ struct TolLds { ParLds p; TolCtx t; };
 // (its out-of-line callee is decode_seq_run_tol, which no other kernel calls: the register bound can be its own)
 __global__ __launch_bounds__(64, 4) void k_decode_tolerant(DecodeArgs a)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     __shared__ TolLds lds;
     const int blk = a.segFirst + (int)blockIdx.x;
     if (!is_codec_error(uni(a.result[blk]))) {
@@ -528,6 +530,7 @@ enum { RGN_END = 0, RGN_SKIP = 1, RGN_FIX = 2 };
 __global__ __attribute__((amdgpu_flat_work_group_size(RPL_THREADS, RPL_THREADS), amdgpu_waves_per_eu(PAR_WAVES, PAR_WAVES)))
 void k_decode_fixup_regions(DecodeArgs a)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     __shared__ ParLds lds;
     __shared__ ReplayLds rl;
     __shared__ RplCtl ctl;
@@ -694,6 +697,7 @@ __device__ __forceinline__ bool ptr_taken(const DecodeArgs &a, int blk)
 // matches.  Workgroup 0: the bytes in front of the segment (caller's dictionary, block before the segment).
 __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     uint32_t *P = a.ptr;
     const int tid = (int)threadIdx.x;
     const uint64_t lo = ptr_lo(a);
@@ -821,6 +825,7 @@ static unsigned ptr_grid(int n) { return (unsigned)((n + 8 * PTR_RUN - 1) / (8 *
 // pointers another thread is updating are harmless: every value a pointer ever holds is an ancestor.
 __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsigned items)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     // passes behind the first: only if the chasing fetch left something, and the pass before changed something
     if (pass > 0 && !(ctl->changed[PTR_MAX_PASSES] && ctl->changed[pass - 1])) return;
@@ -927,6 +932,7 @@ __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsign
 template <bool CHASE>
 __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     if (!CHASE && !ctl->changed[PTR_MAX_PASSES]) return;
     const uint32_t *P = a.ptr;
@@ -1014,6 +1020,7 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
 // ... and only then do the results change: the passes above tell a dependent block by its standalone result.
 __global__ __launch_bounds__(256) void k_ptr_finish(DecodeArgs a)
 {
+    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
     const int blk = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
     if (blk < a.segEnd && ptr_taken(a, blk)) a.result[blk] = a.tolSize[blk];
 }

@@ -79,6 +79,7 @@ def _load():
     sig("mi355lz4_synchronize", C.c_int, vp)
     sig("mi355lz4_set_decoder", C.c_int, vp, C.c_int)
     sig("mi355lz4_set_segments", C.c_int, vp, C.c_int)
+    sig("mi355lz4_set_linked_async", C.c_int, vp, C.c_int)
     sig("mi355lz4_set_linked_compress", C.c_int, vp, C.c_int)
     sig("mi355lz4_compress_bound", C.c_int, C.c_int)
     sig("mi355lz4_slot_stride", C.c_size_t, C.c_int, C.c_int)
@@ -146,7 +147,7 @@ lib = _load()
 # every symbol include/mi355lz4.h and include/lz4.h declare (checked by tests without a GPU)
 DECLARED_SYMBOLS = [
     "mi355lz4_version", "mi355lz4_last_error", "mi355lz4_device_count", "mi355lz4_create", "mi355lz4_destroy",
-    "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder", "mi355lz4_set_segments", "mi355lz4_set_linked_compress",
+    "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder", "mi355lz4_set_segments", "mi355lz4_set_linked_async", "mi355lz4_set_linked_compress",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
     "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_decompress_linked_begin",
     "mi355lz4_decompress_linked_end", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
@@ -293,6 +294,10 @@ class Engine:
     def set_linked_compress(self, on):
         """Compress calls write ONE linked stream (previous block = dictionary), like the reference's compressor."""
         lib.slz4_engine_set_linked_compress(self._h, int(bool(on)))
+
+    def set_linked_async(self, max_decoded_block_size):
+        """Linked device decodes enqueue only, no host wait (include/mi355lz4.h); 0 = default (wait)."""
+        _check(lib.mi355lz4_set_linked_async(self.ctx, int(max_decoded_block_size)), "set_linked_async")
 
     def set_segments(self, segs):
         """Small-batch compression: segments per block (-1 automatic, 0 off, 2..64 forced); include/mi355lz4.h."""

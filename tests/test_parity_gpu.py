@@ -611,6 +611,9 @@ LINKED_VARIANTS = {
     "replay_only": {"MI355LZ4_LINKED_PTR": "0"},
     "replay_segments_of_2": {"MI355LZ4_LINKED_PTR": "0", "MI355LZ4_LINKED_POOL_BLOCKS": "2"},
     "serial_only": {"MI355LZ4_LINKED_POOL_BLOCKS": "0"},
+    # no host wait: the second pass is enqueued over all blocks, gated on the device (mi355lz4_set_linked_async)
+    "async": {"MI355LZ4_LINKED_ASYNC": "4194304"},
+    "async_segments_of_3": {"MI355LZ4_LINKED_ASYNC": "4194304", "MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
 }
 
 
