@@ -496,9 +496,11 @@ static int encode_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *sr
             DevBuf *sb = nullptr;
             for (int i = 0; i < c->nSeg; i++) if (c->seg[i].s == c->stream) sb = &c->seg[i].b;
             if (!sb && c->nSeg < 4) { c->seg[c->nSeg].s = c->stream; sb = &c->seg[c->nSeg++].b; }
-            if (sb && dev_reserve(*sb, listBytes + cntBytes + 64) == 0) {
+            if (sb && dev_reserve(*sb, listBytes + 3 * cntBytes + 256) == 0) {
                 sa.lists = (uint64_t *)sb->p;
                 sa.segCount = (uint32_t *)((uint8_t *)sb->p + ((listBytes + 63) & ~(size_t)63));
+                sa.segBytes = sa.segCount + (size_t)nBlocks * (size_t)segs;
+                sa.segPrevEnd = (int32_t *)(sa.segBytes + (size_t)nBlocks * (size_t)segs);
                 launch_encode_seg(sa, c->stream);
                 return check_launch("encode launch");
             }

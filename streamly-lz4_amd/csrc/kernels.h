@@ -73,6 +73,8 @@ struct EncodeSegArgs {
     uint64_t *lists;             // sequence records: block b's segment j at lists + b * listStride + s0 / 4 + j
     size_t listStride;           // records per block: maxBlockLen / 4 + segs + 1
     uint32_t *segCount;          // records per segment
+    uint32_t *segBytes;          // bytes a segment's records emit to (k_seg_sizes)
+    int32_t *segPrevEnd;         // end of the last sequence in front of the segment
 };
 void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s);
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);

@@ -158,46 +158,102 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PE
     if (lane_id() == 0) a.segCount[(size_t)blk * a.segs + j] = count;
 }
 
+// Emission of a segmented block, every segment by a wave of its own, in two steps: k_seg_sizes measures what each
+// segment's records come to in bytes (a segment's first sequence takes its literals from where the last sequence
+// BEFORE the segment ends), k_emit_seg places every segment behind the ones in front of it.  (One wave per block did
+// this in round 3's first version: 8 ms for a 4 MiB block.)
+__device__ __forceinline__ int seg_prev_end(const EncodeSegArgs &a, int blk, int j, int n)
+{
+    // end of the last sequence in front of segment j (0 when there is none)
+    for (int i = j - 1; i >= 0; i--) {
+        const int cnt = (int)a.segCount[(size_t)blk * a.segs + i];
+        if (cnt > 0) {
+            const int s0 = min(n, i * a.segLen);
+            int start, len, mo;
+            seg_unpack(a.lists[(size_t)blk * a.listStride + (size_t)(s0 / 4 + i) + (size_t)(cnt - 1)], start, len, mo);
+            return start + len;
+        }
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_seg_sizes(EncodeSegArgs a)
+{
+    const int blk = (int)(blockIdx.x / (unsigned)a.segs), j = (int)(blockIdx.x % (unsigned)a.segs);
+    const int lane = lane_id();
+    const int n = a.e.srcLen ? a.e.srcLen[blk] : a.e.uniformLen;
+    const int cnt = (n > 0) ? (int)a.segCount[(size_t)blk * a.segs + j] : 0;
+    const int s0 = min(max(n, 0), j * a.segLen);
+    const uint64_t *list = a.lists + (size_t)blk * a.listStride + (size_t)(s0 / 4 + j);
+    int prevEnd = (n > 0) ? seg_prev_end(a, blk, j, n) : 0;
+    const int prev0 = prevEnd;
+    uint32_t bytes = 0;
+    for (int i0 = 0; i0 < cnt; i0 += LZ4_WAVE) {
+        const int k = min(LZ4_WAVE, cnt - i0);
+        int start = 0, len = 0, mo = 0;
+        if (lane < k) seg_unpack(list[i0 + lane], start, len, mo);
+        const int end = start + len;
+        int qPrev = __builtin_amdgcn_update_dpp(prevEnd, end, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane == 0) qPrev = prevEnd;
+        const uint32_t lit = (uint32_t)(start - qPrev), mc = (uint32_t)(len - LZ4_MINMATCH);
+        const uint32_t esz = (lane < k) ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
+        bytes += (uint32_t)__builtin_amdgcn_readlane(enc_scan_incl((int)esz), 63);
+        prevEnd = __builtin_amdgcn_readlane(end, k - 1);
+    }
+    if (lane == 0) {
+        a.segBytes[(size_t)blk * a.segs + j] = bytes;
+        a.segPrevEnd[(size_t)blk * a.segs + j] = prev0;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_emit_seg(EncodeSegArgs a)
 {
-    const int blk = (int)blockIdx.x;
+    const int blk = (int)(blockIdx.x / (unsigned)a.segs), j = (int)(blockIdx.x % (unsigned)a.segs);
     const int lane = lane_id();
     const uint64_t off = a.e.srcOff ? a.e.srcOff[blk] : (uint64_t)blk * a.e.blockStride;
     const int n = a.e.srcLen ? a.e.srcLen[blk] : a.e.uniformLen;
     uint8_t *slot = a.e.slots + (size_t)blk * a.e.slotStride;
-    uint8_t *op0 = slot + a.e.headerKind, *op = op0;
+    uint8_t *op0 = slot + a.e.headerKind;
     const uint8_t *src = a.e.src + off;
-    int c = 0;
-    if (n == 0) {                                              // cbits/lz4.c:1263-1273: empty input -> single 0 token
-        if (lane == 0) op[0] = 0;
-        c = 1;
-    } else if (n > 0) {
-        int prevEnd = 0;                                       // where the next sequence's literals start
-        for (int j = 0; j < a.segs; j++) {
-            const int cnt = (int)a.segCount[(size_t)blk * a.segs + j];
-            const int s0 = min(n, j * a.segLen);
-            const uint64_t *list = a.lists + (size_t)blk * a.listStride + (size_t)(s0 / 4 + j);
-            for (int i0 = 0; i0 < cnt; i0 += LZ4_WAVE) {
-                const int k = min(LZ4_WAVE, cnt - i0);
-                int start = 0, len = 0, mo = 0;
-                if (lane < k) seg_unpack(list[i0 + lane], start, len, mo);
-                const int end = start + len;
-                // my literals start where the sequence before me ends (lane 0: the one before this batch)
-                int qPrev = __builtin_amdgcn_update_dpp(prevEnd, end, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                if (lane == 0) qPrev = prevEnd;
-                op = emit_sequences(src, op, qPrev, start, len, mo, k);
-                prevEnd = __builtin_amdgcn_readlane(end, k - 1);
-            }
+    const bool lastSeg = j == a.segs - 1;
+    if (n <= 0) {
+        if (lastSeg && lane == 0) {
+            int c = 0;
+            if (n == 0) { op0[0] = 0; c = 1; }                 // cbits/lz4.c:1263-1273: empty input -> single 0 token
+            store_le32(slot, c);
+            if (a.e.headerKind == 8) store_le32(slot + 4, n);
+            a.e.framedLen[blk] = (c > 0) ? a.e.headerKind + c : 0;
         }
-        // ---- last literals (:1204-1231) ----
-        const uint32_t lastRun = (uint32_t)(n - prevEnd);
-        uint8_t *tok = op++;
-        if (lane == 0) *tok = (uint8_t)(min(lastRun, 15u) << 4);
-        if (lastRun >= 15) op = emit_ext_len(op, lastRun - 15);
-        wave_copy_bytes(op, src + prevEnd, lastRun);
-        op += lastRun;
-        c = (int)(op - op0);
+        return;
     }
+    // where this segment's bytes go: behind the segments in front of it (at most 64: one per lane)
+    const uint32_t mine = (lane < j) ? a.segBytes[(size_t)blk * a.segs + lane] : 0u;
+    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane(enc_scan_incl((int)mine), 63);
+    uint8_t *op = op0 + before;
+    const int cnt = (int)a.segCount[(size_t)blk * a.segs + j];
+    const int s0 = min(n, j * a.segLen);
+    const uint64_t *list = a.lists + (size_t)blk * a.listStride + (size_t)(s0 / 4 + j);
+    int prevEnd = a.segPrevEnd[(size_t)blk * a.segs + j];
+    for (int i0 = 0; i0 < cnt; i0 += LZ4_WAVE) {
+        const int k = min(LZ4_WAVE, cnt - i0);
+        int start = 0, len = 0, mo = 0;
+        if (lane < k) seg_unpack(list[i0 + lane], start, len, mo);
+        const int end = start + len;
+        // my literals start where the sequence before me ends (lane 0: the one before this batch)
+        int qPrev = __builtin_amdgcn_update_dpp(prevEnd, end, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane == 0) qPrev = prevEnd;
+        op = emit_sequences(src, op, qPrev, start, len, mo, k);
+        prevEnd = __builtin_amdgcn_readlane(end, k - 1);
+    }
+    if (!lastSeg) return;
+    // ---- the block's last segment: last literals (:1204-1231), header ----
+    const uint32_t lastRun = (uint32_t)(n - prevEnd);
+    uint8_t *tok = op++;
+    if (lane == 0) *tok = (uint8_t)(min(lastRun, 15u) << 4);
+    if (lastRun >= 15) op = emit_ext_len(op, lastRun - 15);
+    wave_copy_bytes(op, src + prevEnd, lastRun);
+    op += lastRun;
+    const int c = (int)(op - op0);
     if (lane == 0) {
         store_le32(slot, c);                                   // Internal/LZ4.hs:262
         if (a.e.headerKind == 8) store_le32(slot + 4, n);      // Internal/LZ4.hs:261
@@ -208,8 +264,10 @@ __global__ __launch_bounds__(64) void k_emit_seg(EncodeSegArgs a)
 void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s)
 {
     if (a.e.nBlocks <= 0) return;
-    hipLaunchKernelGGL(k_encode_seg, dim3((unsigned)a.e.nBlocks * (unsigned)a.segs), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_emit_seg, dim3((unsigned)a.e.nBlocks), dim3(64), 0, s, a);
+    const dim3 grid((unsigned)a.e.nBlocks * (unsigned)a.segs);
+    hipLaunchKernelGGL(k_encode_seg, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_seg_sizes, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_emit_seg, grid, dim3(64), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------
