@@ -435,6 +435,47 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             return total;
         };
 
+        // The tail of a window -- catch up and parking the selected sequences in the queue, which touch neither the
+        // table nor the anchor -- is put off until the NEXT window has issued its requests: it then runs while those
+        // are in flight instead of in front of them (the wave's chain of dependent waits per window is what its rate
+        // follows: 16 waves per CU, each waiting two thirds of the time).
+        uint64_t tSelm = 0;                                  // pending tail: selected lanes (0 = none pending)
+        int tP0 = 0, tPrevEnd = 0, tMl = 0, tBack = 0;       // its window, and per lane: literal start, match length, equal bytes before
+        uint32_t tCand = 0;
+        // ... in two halves, so that its four cross-lane moves travel with the next window's table reads (one LDS round
+        // trip for both) and are only looked at once that window's requests are out.  Without a pending tail (tSelm = 0)
+        // both halves do nothing: no branch, so that the compiler can interleave them with the window's own code.
+        int tR0 = 0, tR1 = 0, tR2 = 0, tR3 = 0, tK = 0;
+        auto tail_issue = [&]() {
+            const uint64_t selm = tSelm;
+            const bool sel = (selm >> lane) & 1ull;
+            const int myPos = tP0 + lane;
+            // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
+            // are known equal, the head's group measured up to 8 more before the head ----
+            int mstart = myPos, mcand = (int)tCand;
+            if (sel) {
+                const int room = min(mstart - tPrevEnd, mcand);
+                const int back = min(room, tBack);
+                mstart -= back; mcand -= back;
+            }
+            // ---- park the selected sequences in the queue (stable compaction, one ds_permute per field) ----
+            tK = (int)__builtin_popcountll(selm);
+            if (qCnt + tK > LZ4_WAVE) flush_queue();
+            const int rk = (int)enc_mbcnt(selm);
+            const int dest = (sel ? qCnt + rk : qCnt + tK + (lane - rk)) & 63;
+            tR0 = __builtin_amdgcn_ds_permute(dest << 2, tPrevEnd);
+            tR1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
+            tR2 = __builtin_amdgcn_ds_permute(dest << 2, myPos + tMl - mstart);
+            tR3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
+            tSelm = 0;
+        };
+        auto tail_commit = [&]() {
+            if (lane >= qCnt && lane < qCnt + tK) { qPrev = tR0; qStart = tR1; qLen = tR2; qOff = tR3; }
+            qCnt += tK;
+            tK = 0;
+        };
+        auto window_tail = [&]() { tail_issue(); tail_commit(); };
+
         // one window: positions [p0, p0 + 64), p0 >= anchor; returns where the next one starts
         auto group_window = [&](const int p0) -> int {
             // ---- A: probe ----
@@ -444,7 +485,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const uint32_t h = hx >> 4, tg = hx & 15u;
             const uint32_t tsh = (hx >> 2) & 28u;                 // (h & 7) * 4
             uint32_t *tagw = &tags[hx >> 7];                      // h >> 3
-            const uint32_t oldp = table[h], oldt = (*tagw >> tsh) & 15u;
+            const uint32_t oldp = table[h], tagWord = *tagw;
+            tail_issue();                                      // the window before this one: its cross-lane moves ride along
+            const uint32_t oldt = (tagWord >> tsh) & 15u;
             uint32_t cand = 0;
             const bool candOk = tab_candidate<TabT, DICT>((TabT)oldp, myPos, cand) && oldt == tg && cand >= 8u;
             // run heads: a candidate that continues its left neighbour's belongs to the same copied region
@@ -476,6 +519,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 b1 = load16(gv ? c + j16m8 : p0);
             }
             ENC_LAP(0);
+            tail_commit();                                     // (the requests are out: the moves' results are looked at now)
             // ---- C: finish ----
             uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a0, b0));
             if (twoRounds) {
@@ -536,31 +580,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
-            // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
-            // are known equal, the head's group measured up to 8 more before the head ----
-            int mstart = myPos, mcand = (int)cand;
-            if (sel) {
-                const int room = min(mstart - prevEnd, mcand);
-                const int back = min(room, delta + (int)((hv >> 8) & 15u));
-                mstart -= back; mcand -= back;
-            }
-            ENC_LAP(4);
-            // ---- park the selected sequences in the queue (stable compaction, one ds_permute per field) ----
-            {
-                const int k = (int)__builtin_popcountll(selm);
-                if (qCnt + k > LZ4_WAVE) flush_queue();
-                const int rk = (int)enc_mbcnt(selm);
-                const int dest = (sel ? qCnt + rk : qCnt + k + (lane - rk)) & 63;
-                const int r0 = __builtin_amdgcn_ds_permute(dest << 2, prevEnd);
-                const int r1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
-                const int r2 = __builtin_amdgcn_ds_permute(dest << 2, myPos + (int)myMl - mstart);
-                const int r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
-                if (lane >= qCnt && lane < qCnt + k) { qPrev = r0; qStart = r1; qLen = r2; qOff = r3; }
-                qCnt += k;
-            }
+            // ---- catch up and the queue: put off (window_tail) ----
+            tSelm = selm; tP0 = p0; tPrevEnd = prevEnd; tMl = (int)myMl; tCand = cand;
+            tBack = delta + (int)((hv >> 8) & 15u);
             anchor = pEnd;
             missAcc = miss0;
-            ENC_LAP(5);
 #ifdef ENC_STATS
             est[6] += 1;
 #endif
@@ -574,6 +598,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 if (pipe_can_issue((int)p)) {
                     int np = (int)p;
                     do np = group_window(np); while (pipe_can_issue(np));
+                    window_tail();
                     p = np;
                     continue;
                 }
