@@ -16,6 +16,8 @@ static int TAGBITS = 4;        // bits of tag compared
 static int DEPTH = 2;          // pipe: windows in flight
 static int BACKCAP = 8;        // head measures up to 8 bytes before itself
 static int WIN = 64;
+static int HEADCAP = 1000;      // heads per 64-position window that get a group (the kernel: 32)
+static int END2MIN = 0;        // ... only behind matches of at least this length
 static int END2 = 0;           // cur: also register (match end - 2), as the reference does (:1146)
 static int MINC = 0;           // cur: candidates below this position are not taken
 static long g_windows, g_heads, g_seqs, g_hits, g_ext2, g_hist[65], g_known;
@@ -60,14 +62,14 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                     candOk[l] = cand[l] < (uint32_t)pos && (table[h[l]].tag & tmask) == tg[l] && cand[l] >= (uint32_t)MINC;
                     if (!table[h[l]].used && cand[l] == 0 && pos > 0) candOk[l] = (0 == tg[l]);   // zeroed table: tag 0, pos 0
                 }
-                int hd = 0;
+                int hd = 0, nhd = 0;
                 for (int l = 0; l < WIN; l++) {
                     int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
                     head[l] = candOk[l] && !contin;
                     if (head[l]) {
-                        hd = l; g_heads++;
+                        hd = l; g_heads++; nhd++;
                         int pos = p0 + l;
-                        if (rd32(src + pos) == rd32(src + cand[l])) {
+                        if (nhd <= HEADCAP && rd32(src + pos) == rd32(src + cand[l])) {
                             hit[l] = 1;
                             int maxLen = matchlimit - pos;
                             int m = count_fwd(src, pos, cand[l], matchlimit);
@@ -107,7 +109,7 @@ static int sim_cur(const uint8_t *src, int n, int accel)
                     // covered: strictly inside a selected match
                     int covered = 0;
                     for (int q = l - 1; q >= 0; q--) if (sel[q]) { covered = pos < p0 + q + (int)ml[q]; break; }
-                    int end2 = 0; if (END2) for (int q = l - 1; q >= 0; q--) if (sel[q]) { end2 = pos == p0 + q + (int)ml[q] - 2; break; }
+                    int end2 = 0; if (END2) for (int q = l - 1; q >= 0; q--) if (sel[q]) { end2 = pos == p0 + q + (int)ml[q] - 2 && (int)ml[q] >= END2MIN; break; }
                     if (valid[l] && (!covered || end2) && pos < nextP) { table[h[l]].pos = (uint16_t)pos; table[h[l]].tag = tg[l]; table[h[l]].used = 1; }
                     if (sel[l]) {
                         int mstart = pos, mcand = (int)cand[l];
@@ -245,6 +247,90 @@ static int sim_pipe(const uint8_t *src, int n, int accel)
     return (int)out;
 }
 
+
+// ------------------------------------------------------------------ pair form (round 3, ENC_PAIR)
+// Two windows per step: both probed with every position written at once (W0 then W1), finished in order, covered
+// positions take their insertion back (W1 first), the next pair starts at the end of the last selected match.
+static int LATECONTIN = 0;      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
+static int sim_pair(const uint8_t *src, int n, int accel)
+{
+    static Ent table[4096];
+    memset(table, 0, sizeof(table));
+    long out = 0; int anchor = 0;
+    if (n == 0) return 1;
+    const uint32_t tmask = (1u << TAGBITS) - 1u;
+    (void)accel;
+    if (n >= 13) {
+        const int mfl = n - 11, matchlimit = n - 5;
+        int p0 = 0;
+        while (p0 + 128 <= mfl) {
+            int valid[128], candOk[128], hit[128], myHead[128], headOf[128], late[128]; uint32_t h[128], tg[128], cand[128], ml[128], hback[128]; Ent old[128];
+            for (int w = 0; w < 2; w++) {
+                for (int l = 64 * w; l < 64 * w + 64; l++) {
+                    int pos = p0 + l; valid[l] = 1;
+                    uint32_t hx = hash16(src + pos); h[l] = hx >> 8; tg[l] = (hx >> (8 - TAGBITS)) & tmask;
+                    old[l] = table[h[l]]; cand[l] = old[l].pos;
+                    candOk[l] = old[l].used && cand[l] < (uint32_t)pos && (old[l].tag & tmask) == tg[l] && cand[l] >= 8;
+                }
+                for (int l = 64 * w; l < 64 * w + 64; l++) {
+                    int contin = candOk[l] && l > 64 * w && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
+                    late[l] = LATECONTIN && w == 0 && contin;
+                    if (!late[l]) { Ent e = { (uint16_t)(p0 + l), (uint8_t)tg[l], 1 }; table[h[l]] = e; }
+                }
+            }
+            g_windows += 2;
+            int hd = 0, nh[2] = {0, 0};
+            for (int l = 0; l < 128; l++) {
+                hit[l] = 0; ml[l] = 0; hback[l] = 0; headOf[l] = 0;
+                int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
+                int head = candOk[l] && !contin;
+                int pos = p0 + l;
+                if (head) {
+                    hd = l; headOf[l] = 1; nh[l >> 6]++; g_heads++;
+                    if (nh[l >> 6] <= HEADCAP && rd32(src + pos) == rd32(src + cand[l])) {
+                        hit[l] = 1;
+                        int maxLen = matchlimit - pos;
+                        int m = count_fwd(src, pos, cand[l], matchlimit);
+                        ml[l] = m < maxLen ? m : maxLen;
+                        int b = 0;
+                        while (b < BACKCAP && b < (int)cand[l] && b < pos && src[pos - 1 - b] == src[cand[l] - 1 - b]) b++;
+                        hback[l] = b;
+                    }
+                }
+                myHead[l] = hd;
+                if (contin) {
+                    int m = (int)ml[hd] - (l - hd);
+                    hit[l] = hit[hd] && m >= 4; ml[l] = hit[l] ? m : 0; hback[l] = hback[hd];
+                }
+            }
+            int covered[128], pEnd = anchor, any = 0;
+            for (int l = 0; l < 128; l++) {
+                int pos = p0 + l;
+                covered[l] = pos < pEnd;
+                if (pos < pEnd || !hit[l]) continue;
+                int mstart = pos, mcand = (int)cand[l];
+                int room = mstart - pEnd; if (mcand < room) room = mcand;
+                int back = (l - myHead[l]) + (int)hback[l]; if (room < back) back = room;
+                mstart -= back;
+                out += seq_size(mstart - pEnd, pos + (int)ml[l] - mstart); g_seqs++; any = 1;
+                pEnd = pos + (int)ml[l];
+            }
+            for (int l = 127; l >= 0; l--) {
+                Ent *e = &table[h[l]];
+                if (late[l]) { if (!covered[l] && (!e->used || e->pos < (uint16_t)(p0 + l))) { Ent x = { (uint16_t)(p0 + l), (uint8_t)tg[l], 1 }; *e = x; } }
+                else if (covered[l]) { if (e->used && e->pos == (uint16_t)(p0 + l)) *e = old[l]; }
+            }
+            if (any) anchor = pEnd;
+            p0 = p0 + 128 > pEnd ? p0 + 128 : pEnd;
+        }
+        // the rest of the block: the serial windows (as sim_cur), sharing the table
+        // (approximation for the last < 128 positions: literals)
+    }
+    int last = n - anchor;
+    out += 1 + last + (last >= 15 ? (last - 15) / 255 + 1 : 0);
+    return (int)out;
+}
+
 int main(int argc, char **argv)
 {
     const char *kind = argc > 1 ? argv[1] : "lzsynth";
@@ -267,9 +353,11 @@ int main(int argc, char **argv)
         (double)g_windows / nb, (double)g_heads / (g_windows ? g_windows : 1), (double)g_hits / (g_windows ? g_windows : 1), (double)g_seqs / nb, (double)g_ext2 / (g_windows ? g_windows : 1)); } while (0)
     TAGBITS = 4; RUN("cur tag4", sim_cur(blocks[b], bl, 1));
     TAGBITS = 4; END2 = 1; RUN("cur tag4 +end2", sim_cur(blocks[b], bl, 1)); END2 = 0;
+    TAGBITS = 4; END2 = 1; END2MIN = 24; RUN("cur tag4 +end2 (len>=24)", sim_cur(blocks[b], bl, 1)); END2MIN = 40; RUN("cur tag4 +end2 (len>=40)", sim_cur(blocks[b], bl, 1)); END2MIN = 20; RUN("cur tag4 +end2 (len>=20)", sim_cur(blocks[b], bl, 1)); END2MIN = 16; RUN("cur tag4 +end2 (len>=16)", sim_cur(blocks[b], bl, 1)); END2MIN = 12; RUN("cur tag4 +end2 (len>=12)", sim_cur(blocks[b], bl, 1)); END2 = 0; END2MIN = 0;
     TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
     TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
     TAGBITS = 4; WIN = 128; RUN("cur tag4 win128", sim_cur(blocks[b], bl, 1)); WIN = 64;
+    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; HEADCAP = 1000;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)

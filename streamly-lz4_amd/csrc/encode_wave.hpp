@@ -104,6 +104,10 @@ __device__ __forceinline__ int enc_scan_incl(int x)
     return x;
 }
 
+#ifndef ENC_END2_MINLEN
+#define ENC_END2_MINLEN 16        // forward length from which a match also registers (its end - 2), as the reference does behind every match
+#endif
+
 // leading zero BYTES (0..16) of a 16-byte xor, without branches: v_ffbl_b32 gives 0..31, or ~0 for a zero word, so
 // "or"-ing each word's bit offset in keeps ~0 for the zero words and the minimum is the first set bit of the 128
 __device__ __forceinline__ uint32_t ffbl32(uint32_t x)        // v_ffbl_b32: ~0 when x == 0
@@ -269,7 +273,8 @@ __device__ __forceinline__ bool tab_candidate(TabT e, int myPos, uint32_t &cand)
 // The wave then writes sequence RECORDS to seg->list instead of bytes, starts no match within the last 12 bytes of its
 // segment (a match may END at the seam; only the block's last segment keeps the last 5 bytes as literals) and leaves
 // its trailing literals to the segment behind it: the return value is the position (block-relative) where they start.
-template <typename TabT, bool DICT = false, bool SEG = false>
+// PAIR: the dense windows go two to a step (see "Two windows per step" below); false: one window per step.
+template <typename TabT, bool DICT = false, bool SEG = false, bool PAIR = false>
 __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int accel, TabT *table,
                                  unsigned long long *stats = nullptr, int dictLen = 0, SegOut *seg = nullptr)
 {
@@ -410,6 +415,24 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             return total | (back << 8) | ((uint32_t)(f >= (uint32_t)LZ4_MINMATCH) << 12) | ((uint32_t)(total == 56u) << 13);
         };
 
+        // heads beyond the 32nd of a window (two rounds of 16 groups are requested up front): one more round of groups at
+        // a time, requested and waited for here.  Generated text has 14-17 heads per window; source code 25-27, and
+        // leaving the heads past the 32nd without a match cost 2 % of its ratio (oracle/sim_encode2.c, headcap32).
+        auto more_rounds = [&](const int p0w, const uint64_t headm, const bool head, const uint32_t rank4, const uint32_t cand, uint32_t r) -> uint32_t {
+            const int nH = (int)__builtin_popcountll(headm);
+            for (int rr = 2; rr * 16 < nH; rr++) {
+                const int dest = (head && (int)(rank4 >> 8) == rr) ? (int)(rank4 & 255u) : 4;
+                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | cand)), 0);
+                const bool gv = (int)gi < 0;
+                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
+                const dev_v4 a = load16(gv ? p0w + hl + j16m8 : p0w);
+                const dev_v4 b = load16(gv ? c + j16m8 : p0w);
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a, b));
+                if ((int)(rank4 >> 8) == rr) r = r2;
+            }
+            return r;
+        };
+
         // a match that reached the horizon: the whole wave counts on, 16 bytes a lane
         auto extend_long = [&](const int pe, const int ce) -> int {
             int total = 0;
@@ -439,40 +462,70 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // table nor the anchor -- is put off until the NEXT window has issued its requests: it then runs while those
         // are in flight instead of in front of them (the wave's chain of dependent waits per window is what its rate
         // follows: 16 waves per CU, each waiting two thirds of the time).
-        uint64_t tSelm = 0;                                  // pending tail: selected lanes (0 = none pending)
-        int tP0 = 0, tPrevEnd = 0, tMl = 0, tBack = 0;       // its window, and per lane: literal start, match length, equal bytes before
-        uint32_t tCand = 0;
+        struct Tail {                                        // a window's pending tail
+            uint64_t selm = 0;                               // selected lanes (0 = nothing pending)
+            int p0 = 0, prevEnd = 0, ml = 0, back = 0;       // its window, and per lane: literal start, match length, equal bytes before
+            uint32_t cand = 0;
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0, k = 0;       // the cross-lane moves under way
+        } tl[2];                                             // (two: the pair form below finishes two windows at a time)
         // ... in two halves, so that its four cross-lane moves travel with the next window's table reads (one LDS round
-        // trip for both) and are only looked at once that window's requests are out.  Without a pending tail (tSelm = 0)
+        // trip for both) and are only looked at once that window's requests are out.  Without a pending tail (selm = 0)
         // both halves do nothing: no branch, so that the compiler can interleave them with the window's own code.
-        int tR0 = 0, tR1 = 0, tR2 = 0, tR3 = 0, tK = 0;
-        auto tail_issue = [&]() {
-            const uint64_t selm = tSelm;
+        auto tail_issue1 = [&](Tail &t, const int qBase) {
+            const uint64_t selm = t.selm;
             const bool sel = (selm >> lane) & 1ull;
-            const int myPos = tP0 + lane;
+            const int myPos = t.p0 + lane;
             // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
             // are known equal, the head's group measured up to 8 more before the head ----
-            int mstart = myPos, mcand = (int)tCand;
+            int mstart = myPos, mcand = (int)t.cand;
             if (sel) {
-                const int room = min(mstart - tPrevEnd, mcand);
-                const int back = min(room, tBack);
+                const int room = min(mstart - t.prevEnd, mcand);
+                const int back = min(room, t.back);
                 mstart -= back; mcand -= back;
             }
             // ---- park the selected sequences in the queue (stable compaction, one ds_permute per field) ----
-            tK = (int)__builtin_popcountll(selm);
-            if (qCnt + tK > LZ4_WAVE) flush_queue();
+            t.k = (int)__builtin_popcountll(selm);
             const int rk = (int)enc_mbcnt(selm);
-            const int dest = (sel ? qCnt + rk : qCnt + tK + (lane - rk)) & 63;
-            tR0 = __builtin_amdgcn_ds_permute(dest << 2, tPrevEnd);
-            tR1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
-            tR2 = __builtin_amdgcn_ds_permute(dest << 2, myPos + tMl - mstart);
-            tR3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
-            tSelm = 0;
+            const int dest = (sel ? qBase + rk : qBase + t.k + (lane - rk)) & 63;
+            t.r0 = __builtin_amdgcn_ds_permute(dest << 2, t.prevEnd);
+            t.r1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
+            t.r2 = __builtin_amdgcn_ds_permute(dest << 2, myPos + t.ml - mstart);
+            t.r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
+            t.selm = 0;
+        };
+        auto tail_commit1 = [&](Tail &t) {
+            if (lane >= qCnt && lane < qCnt + t.k) { qPrev = t.r0; qStart = t.r1; qLen = t.r2; qOff = t.r3; }
+            qCnt += t.k;
+            t.k = 0;
+        };
+        bool tailSplit = false;                              // the two pending tails did not fit the queue together
+        auto tail_issue = [&]() {
+            if constexpr (!PAIR) {
+                if (qCnt + (int)__builtin_popcountll(tl[0].selm) > LZ4_WAVE) flush_queue();
+                tail_issue1(tl[0], qCnt);
+                return;
+            }
+            const int k0 = (int)__builtin_popcountll(tl[0].selm), k1 = PAIR ? (int)__builtin_popcountll(tl[1].selm) : 0;
+            if (qCnt + k0 + k1 > LZ4_WAVE) {
+                // (rare: once per 64 sequences) one after the other, with the queue written out in between
+                if (qCnt + k0 > LZ4_WAVE) flush_queue();
+                tail_issue1(tl[0], qCnt); tail_commit1(tl[0]);
+                if constexpr (PAIR) {
+                    if (qCnt + k1 > LZ4_WAVE) flush_queue();
+                    tail_issue1(tl[1], qCnt); tail_commit1(tl[1]);
+                }
+                tailSplit = true;
+                return;
+            }
+            tailSplit = false;
+            tail_issue1(tl[0], qCnt);
+            if constexpr (PAIR) tail_issue1(tl[1], qCnt + k0);
         };
         auto tail_commit = [&]() {
-            if (lane >= qCnt && lane < qCnt + tK) { qPrev = tR0; qStart = tR1; qLen = tR2; qOff = tR3; }
-            qCnt += tK;
-            tK = 0;
+            if constexpr (!PAIR) { tail_commit1(tl[0]); return; }
+            if (tailSplit) { tailSplit = false; return; }
+            tail_commit1(tl[0]);
+            if constexpr (PAIR) tail_commit1(tl[1]);
         };
         auto window_tail = [&]() { tail_issue(); tail_commit(); };
 
@@ -531,7 +584,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #endif
             // every lane learns its run's head (lane and result) with a max-scan: head lanes put (lane + 1) << 16 | result
             // in, the others 0, and the largest value at or below a lane belongs to the nearest head below it
-            const uint32_t hv = enc_scan_max(head ? (((uint32_t)lane + 1u) << 16) | (rank4 < 512u ? r : 0u) : 0u);   // heads beyond the 32nd: no match
+#ifndef ENC_EXP_NOMORE
+            if (headm >> 32 && __builtin_popcountll(headm) > 32) r = more_rounds(p0, headm, head, rank4, cand, r);
+#endif
+            const uint32_t hv = enc_scan_max(head ? (((uint32_t)lane + 1u) << 16) | r : 0u);
             const int delta = lane + 1 - (int)(hv >> 16);                 // lanes between my run's head and me
             const int m0 = (int)(hv & 0xffu) - delta;
             const bool hit = candOk && ((hv >> 12) & 1u) && m0 >= LZ4_MINMATCH;
@@ -552,6 +608,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             uint64_t selm = 0;
             int pEnd = anchor;
             int prevEnd = anchor;              // end of the selected match before me (selected lanes: my literal start)
+            bool longBefore = false;           // ... and that match is a long one
             for (uint64_t hm = hitm; hm;) {
                 const int k = (int)__builtin_ctzll(hm);
                 int len = __builtin_amdgcn_readlane((int)myMl, k);
@@ -562,7 +619,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 const int endk = p0 + k + len;
                 selm |= 1ull << k;
                 pEnd = endk;
-                if (lane > k) prevEnd = endk;
+                if (lane > k) { prevEnd = endk; longBefore = len >= ENC_END2_MINLEN; }
                 const int sh = endk - p0;
                 hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
             }
@@ -574,15 +631,18 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             else pfPos = -1;
             ENC_LAP(2);
             // ---- table: the probed positions outside the selected matches (:998) ----
-            if (sel || myPos >= prevEnd) {
+            // (... and, like the reference behind every match (:1146), the position two bytes in front of the end of a
+            // LONG match: behind every match it costs text 1.7 % of its ratio, behind matches of 16 bytes and more it
+            // costs nothing there and buys lzsynth 0.13 %)
+            if (sel || myPos >= prevEnd || (longBefore && myPos == prevEnd - 2)) {
                 table[h] = (TabT)myPos;
                 lds_mskor(tagw, 15u << tsh, tg << tsh);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
             // ---- catch up and the queue: put off (window_tail) ----
-            tSelm = selm; tP0 = p0; tPrevEnd = prevEnd; tMl = (int)myMl; tCand = cand;
-            tBack = delta + (int)((hv >> 8) & 15u);
+            tl[0].selm = selm; tl[0].p0 = p0; tl[0].prevEnd = prevEnd; tl[0].ml = (int)myMl; tl[0].cand = cand;
+            tl[0].back = delta + (int)((hv >> 8) & 15u);
             anchor = pEnd;
             missAcc = miss0;
 #ifdef ENC_STATS
@@ -590,14 +650,203 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #endif
             return nextP;
         };
+
+        // ===================================================================================================
+        // Two windows per step (positions [p0, p0 + 128)).  A window is a chain of dependent waits -- table, groups,
+        // requests, lengths, selection -- and the chip has room for 16 such chains per CU (the table's LDS); the rate
+        // follows the number of chains, not the instructions.  Here one chain carries two windows, step by step side by
+        // side, so that each wait is paid once for both.  What the second window needs from the first is the table:
+        // every position of a window is written into its bucket when it is probed (the bucket's previous entry kept in
+        // a register), and positions that end up strictly inside a selected match take that back, last window first,
+        // before the next pair starts -- between pairs the table is the reference's (:998), within a pair the second
+        // window also sees the first one's covered positions (oracle/sim_encode2.c: the ratio goes UP, 2.895 -> 2.91).
+        // ===================================================================================================
+        struct PW {
+            uint32_t hx, oldp, tagWord, cand, cv;
+            bool candOk, head, twoRounds;
+            uint64_t headm, selm;
+            uint32_t rank4, gi0, hv, myMl;
+            int prevEnd, delta;
+            bool keep2;                      // the selected match before me is a long one: its end - 2 stays registered (:1146)
+            dev_v4 a0, b0, a1, b1;
+        };
+        uint64_t pfV8b = 0;                                  // the second window's bytes (window at pfPos + 64)
+        int pfPosB = -2;                                     // ... valid when pfPosB == pfPos (only this form requests them)
+        // (What it costs: the second window meets the first one's positions in the table before the covered ones are
+        // taken back -- lzsynth 2.891 -> 2.888, source text -0.5 % in the simulation -- which the registration behind
+        // long matches below more than gives back on lzsynth.  The template parameter PAIR picks the form: blocks above 64 KiB, whose positions are modular, and segments run one
+        // window per step.)
+        auto pair_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 + 200 <= n && pipeFits; };
+        auto pw_probe = [&](PW &W, const int p0w, const uint64_t v8) {
+            const uint32_t hx = hash5x(v8);
+            const uint32_t h = hx >> 4, tg = hx & 15u, tsh = (hx >> 2) & 28u;
+            uint32_t *tagw = &tags[hx >> 7];
+            W.hx = hx;
+            W.oldp = table[h];
+            W.tagWord = *tagw;
+            table[h] = (TabT)(p0w + lane);                     // every position, at once: the window behind this one probes next
+            lds_mskor(tagw, 15u << tsh, tg << tsh);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
+        auto pw_heads = [&](PW &W, const int p0w, const uint32_t cvBefore) {
+            const uint32_t tg = W.hx & 15u, tsh = (W.hx >> 2) & 28u;
+            const uint32_t oldt = (W.tagWord >> tsh) & 15u;
+            uint32_t cand = 0;
+            W.candOk = tab_candidate<TabT, DICT>((TabT)W.oldp, p0w + lane, cand) && oldt == tg && cand >= 8u;
+            W.cand = cand;
+            W.cv = W.candOk ? cand : 0xffffffffu;
+            // (lane 0 continues the run of the last lane of the window before it)
+            const uint32_t prevCand = (uint32_t)__builtin_amdgcn_update_dpp((int)cvBefore, (int)W.cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            W.head = W.candOk && cand != prevCand + 1u;
+            W.headm = __ballot(W.head);
+            W.twoRounds = (W.headm >> 16) != 0ull && __builtin_popcountll(W.headm) > 16;
+            W.rank4 = enc_mbcnt(W.headm) << 4;
+            const int dest = (W.head && W.rank4 < 256u) ? (int)W.rank4 : 4;
+            W.gi0 = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | cand));
+        };
+        auto pw_loads = [&](PW &W, const int p0w) {
+            {
+                const uint32_t gi = quad(W.gi0, 0);
+                const bool gv = (int)gi < 0;
+                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
+                W.a0 = load16(gv ? p0w + hl + j16m8 : p0w);
+                W.b0 = load16(gv ? c + j16m8 : p0w);
+            }
+            if (W.twoRounds) {
+                const int dest = (W.head && (W.rank4 >> 8) == 1u) ? (int)(W.rank4 & 255u) : 4;
+                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.cand)), 0);
+                const bool gv = (int)gi < 0;
+                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
+                W.a1 = load16(gv ? p0w + hl + j16m8 : p0w);
+                W.b1 = load16(gv ? c + j16m8 : p0w);
+            }
+        };
+        // lengths: laneBase numbers the lanes of the pair 0..127; hvBefore = the scan value of the last lane of the
+        // window before (its run may go on into this window)
+        auto pw_lengths = [&](PW &W, const int p0w, const int laneBase, const uint32_t hvBefore) {
+            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)groupLen(W.a0, W.b0));
+            if (W.twoRounds) {
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)groupLen(W.a1, W.b1));
+                if (W.rank4 >= 256u) r = r1;
+            }
+#ifdef ENC_STATS
+            est[7] += (unsigned)__builtin_popcountll(W.headm);
+#endif
+#ifndef ENC_EXP_NOMORE
+            if (W.headm >> 32 && __builtin_popcountll(W.headm) > 32) r = more_rounds(p0w, W.headm, W.head, W.rank4, W.cand, r);
+#endif
+            const uint32_t mine = W.head ? (((uint32_t)(laneBase + lane) + 1u) << 16) | r : 0u;
+            W.hv = max(enc_scan_max(mine), hvBefore);
+            W.delta = laneBase + lane + 1 - (int)(W.hv >> 16);
+            const int m0 = (int)(W.hv & 0xffu) - W.delta;
+            const bool hit = W.candOk && ((W.hv >> 12) & 1u) && m0 >= LZ4_MINMATCH;
+            W.myMl = hit ? (uint32_t)m0 : 0u;
+        };
+        // greedy selection in this window, continuing from pEnd (the end of the last selected match so far)
+        auto pw_select = [&](PW &W, const int p0w, int &pEnd) {
+            const bool hit = W.myMl != 0u;
+            uint64_t hitm = __ballot(hit);
+            const uint64_t capm = __ballot(hit && ((W.hv >> 13) & 1u));
+            const int lowcut = pEnd - p0w;
+            if (lowcut > 0) hitm = (lowcut >= LZ4_WAVE) ? 0ull : (hitm & (~0ull << lowcut));
+            uint64_t selm = 0;
+            int prevEnd = pEnd;
+            bool longBefore = false;
+            for (uint64_t hm = hitm; hm;) {
+                const int k = (int)__builtin_ctzll(hm);
+                int len = __builtin_amdgcn_readlane((int)W.myMl, k);
+                if ((capm >> k) & 1ull) {
+                    len += extend_long(p0w + k + len, __builtin_amdgcn_readlane((int)W.cand, k) + len);
+                    if (lane == k) W.myMl = (uint32_t)len;
+                }
+                const int endk = p0w + k + len;
+                selm |= 1ull << k;
+                pEnd = endk;
+                if (lane > k) { prevEnd = endk; longBefore = len >= ENC_END2_MINLEN; }
+                const int sh = endk - p0w;
+                hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
+            }
+            W.selm = selm;
+            W.prevEnd = prevEnd;
+            W.keep2 = longBefore;
+        };
+        // positions strictly inside a selected match take their insertion back if the bucket still holds it
+        auto pw_takeback = [&](PW &W, const int p0w) {
+            const int myPos = p0w + lane;
+            if (!((W.selm >> lane) & 1ull) && myPos < W.prevEnd && !(W.keep2 && myPos == W.prevEnd - 2)) {
+                const uint32_t h = W.hx >> 4;
+                if (table[h] == (TabT)myPos) {
+                    const uint32_t tsh = (W.hx >> 2) & 28u;
+                    table[h] = (TabT)W.oldp;
+                    lds_mskor(&tags[W.hx >> 7], 15u << tsh, ((W.tagWord >> tsh) & 15u) << tsh);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
+        auto pair_window = [&](const int p0) -> int {
+            const int p1 = p0 + LZ4_WAVE;
+            if (pfPos != p0 || pfPosB != p0) {
+                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(p0 + lane));
+                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(p1 + lane));
+            }
+            PW W0, W1;
+            pw_probe(W0, p0, pfV8);
+            pw_probe(W1, p1, pfV8b);
+            tail_issue();                                      // the pair before this one: its cross-lane moves ride along
+            pw_heads(W0, p0, 0xffffffffu);
+            pw_heads(W1, p1, (uint32_t)__builtin_amdgcn_readlane((int)W0.cv, 63));
+            pw_loads(W0, p0);
+            pw_loads(W1, p1);
+            ENC_LAP(0);
+            tail_commit();
+            int pEnd = anchor;
+            pw_lengths(W0, p0, 0, 0u);
+            pw_select(W0, p0, pEnd);
+            pw_lengths(W1, p1, LZ4_WAVE, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
+            pw_select(W1, p1, pEnd);
+            ENC_LAP(1);
+            // the next pair starts at the end of the last match, or where this one ends: its bytes are requested now
+            const int nextP = max(p0 + 2 * LZ4_WAVE, pEnd);
+            pfPos = nextP;
+            pfPosB = -2;
+            if (nextP + 136 <= n) {
+                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
+                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + LZ4_WAVE + lane));
+                pfPosB = nextP;
+            } else if (nextP + 72 <= n) {
+                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
+            } else {
+                pfPos = -1;
+            }
+            ENC_LAP(2);
+            pw_takeback(W1, p1);
+            pw_takeback(W0, p0);
+            ENC_LAP(3);
+            tl[0].selm = W0.selm; tl[0].p0 = p0; tl[0].prevEnd = W0.prevEnd; tl[0].ml = (int)W0.myMl; tl[0].cand = W0.cand;
+            tl[0].back = W0.delta + (int)((W0.hv >> 8) & 15u);
+            tl[1].selm = W1.selm; tl[1].p0 = p1; tl[1].prevEnd = W1.prevEnd; tl[1].ml = (int)W1.myMl; tl[1].cand = W1.cand;
+            tl[1].back = W1.delta + (int)((W1.hv >> 8) & 15u);
+            if (W0.selm | W1.selm) { anchor = pEnd; missAcc = miss0; }
+            else { missAcc += 2 * LZ4_WAVE; pfPos = -1; }
+#ifdef ENC_STATS
+            est[6] += 2;
+#endif
+            return nextP;
+        };
 #endif  // ENC_NO_PIPE
+        (void)group_window; (void)pair_window; (void)pipe_can_issue; (void)pair_can_issue;   // (one form per instantiation)
         while (p < mfl) {
             const int64_t step = (int64_t)(missAcc >> 6);
             if (step == 1) {
 #ifndef ENC_NO_PIPE
-                if (pipe_can_issue((int)p)) {
+                if (PAIR ? pair_can_issue((int)p) : pipe_can_issue((int)p)) {
                     int np = (int)p;
-                    do np = group_window(np); while (pipe_can_issue(np));
+                    if constexpr (PAIR) {
+                        // (the last 200 bytes of a block are left to the windows below)
+                        while (pair_can_issue(np)) np = pair_window(np);
+                    } else {
+                        do np = group_window(np); while (pipe_can_issue(np));
+                    }
                     window_tail();
                     p = np;
                     continue;
