@@ -364,7 +364,9 @@ def main():
             tj = json.load(open(tpath))
             # the PMC figure is per launch of the workload's full-size batch
             traffic = tj.get("%s:%s" % (args.workload, dom)) if NB == WORKLOADS[args.workload][2] and corpus_bytes is None else None
-            traffic_src = "profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of %s)" % tj.get("_commit", "an earlier commit")
+            tcommit = (tj.get("_commits") or {}).get("%s:%s" % (args.workload, dom)) or tj.get("_commit", "an earlier commit")
+            traffic_src = ("profiles/traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, one pass each) of this command "
+                           "at commit %s -- a constant read back here, not measured by this run" % tcommit)
         except Exception:
             traffic = None
     # what a plain device-to-device copy of the same U bytes reaches on this box (read + write)

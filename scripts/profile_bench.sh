@@ -9,6 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+echo "${PROFILE_COMMIT:-}" > "$OUT/commit.txt"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 10 --warmup 2 "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \

@@ -36,7 +36,7 @@ def pmc_avg(path, kernel_sub, counter):
 
 def main():
     tag, workload, key = sys.argv[1:4]
-    rnd = sys.argv[4] if len(sys.argv) > 4 else "r01"
+    rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     base = "%s_bench_%s" % (rnd, workload)
@@ -70,11 +70,22 @@ def main():
         "%s %s: FETCH_SIZE=%.4g KB (x2) + WRITE_SIZE=%.4g KB per launch of %s"
         % (rnd, tag, out["FETCH_SIZE"], out["WRITE_SIZE"], KERNEL_OF[key]))
     t["_notes"] = notes
-    try:
-        import subprocess
-        t["_commit"] = "commit " + subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:
-        pass
+    # every entry names the build it was measured at: the commit recorded next to the profile run (scripts/profile_bench.sh
+    # writes gpurun_out/prof_<tag>/commit.txt on the GPU box from $PROFILE_COMMIT), else the checkout's HEAD
+    commit = None
+    cpath = os.path.join(src, "commit.txt")
+    if os.path.exists(cpath):
+        commit = open(cpath).read().strip() or None
+    if not commit:
+        try:
+            import subprocess
+            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = "unknown"
+    commits = t.get("_commits", {})
+    commits["%s:%s" % (workload, key)] = commit
+    t["_commits"] = commits
+    t.pop("_commit", None)
     json.dump(t, open(tpath, "w"), indent=1)
     print("traffic", traffic)
     with open(stats) as f:
