@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything profiles/rNN_* is made of, in one session on one box at one commit:
+#   PROFILE_COMMIT=<short hash> bash scripts/round_evidence.sh
+# Results land under gpurun_out/evidence/ (and gpurun_out/prof_<tag>/ for the three profiled workloads);
+# scripts/collect_evidence.py then copies the summaries into profiles/.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+E=$R/gpurun_out/evidence
+rm -rf "$E"; mkdir -p "$E"
+echo "${PROFILE_COMMIT:-}" > "$E/commit.txt"
+cd "$R"
+bash scripts/profile_bench.sh dec > "$E/profile_dec.log" 2>&1
+bash scripts/profile_bench.sh cmp --workload compress > "$E/profile_cmp.log" 2>&1
+bash scripts/profile_bench.sh text --workload text > "$E/profile_text.log" 2>&1
+for k in lzsynth text; do bash scripts/pmc_encode.sh $k > "$E/encode_${k}_pmc_instmix.txt" 2>&1; done
+python3 bench.py --workload roundtrip --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_roundtrip.json" 2> "$E/bench_roundtrip.err"
+python3 bench.py --workload random256k --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_random256k.json" 2> "$E/bench_random256k.err"
+python3 bench.py --workload text --steps 20 --warmup 2 --linked-compress --no-cpu-baseline > "$E/bench_text_linked_compress.json" 2> "$E/bench_text_linked_compress.err"
+python3 bench.py --steps 20 --warmup 2 --linked --no-cpu-baseline --no-host-api --no-extra > "$E/bench_linked1.json" 2> "$E/bench_linked1.err"
+python3 bench_matrix.py --synthetic --cpu > "$E/bench_matrix_synthetic.jsonl" 2> "$E/bench_matrix.err"
+python3 scripts/small_enc_latency.py 2>/dev/null | grep -v amdgpu > "$E/small_batch_compress_latency.txt"
+python3 scripts/small_dec_breakdown.py 2>/dev/null | grep accel > "$E/small_call_decompress_breakdown.txt"
+python3 scripts/linked_shard_split.py 4096 2>/dev/null | tail -1 > "$E/linked_shard_split.txt"
+python3 scripts/linked_shard_split.py 1024 2>/dev/null | tail -1 >> "$E/linked_shard_split.txt"
+python3 scripts/linked_async_cost.py 2>/dev/null | grep blocks > "$E/linked_async_cost.txt"
+python3 scripts/realtext_ratio.py 2>/dev/null | grep input > "$E/realtext_ratio.txt"
+python3 scripts/size_vs_ref.py 2>/dev/null | grep segs > "$E/size_vs_reference.txt"
+python3 scripts/host_api_rate.py > "$E/host_api_rate.jsonl" 2>/dev/null
+rm -f gpurun_out/linked_rate.json; python3 -m pytest tests/test_linked_rate_gpu.py -q -m gpu > "$E/linked_rate_test.log" 2>&1
+rm -f gpurun_out/linked_rate.json.prev; cp gpurun_out/linked_rate.json "$E/linked_streams_rate.jsonl" 2>/dev/null
+scripts/kernel_resources.sh > "$E/kernel_resources.txt" 2>&1
+grep -l "Memory access fault" "$E"/* && exit 9
+ls -la "$E" | tail -40

@@ -9,9 +9,12 @@ void launch_decode_seq(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_decode_par(const DecodeArgs &, unsigned long long *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_tolerant(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_resolve(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_linked_resolve_a(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_linked_resolve_b(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_longest_stream(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 size_t tol_region_bytes() { return 65536; }
 void launch_encode(const EncodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_encode_seg(const EncodeSegArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_compact(const uint8_t *, size_t, const int32_t *, int, uint8_t *, size_t, uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_interleave(const uint8_t *, const uint64_t *, int, int, int, uint8_t *, const uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_index(const uint8_t *, uint64_t, const uint64_t *, int, int, int, int32_t *, uint64_t *, hipStream_t) { UNREACHABLE_LAUNCH; }
