@@ -64,6 +64,14 @@ foreign import ccall safe "mi355lz4.h mi355lz4_destroy"
     c_destroy :: Ptr C_Engine -> IO ()
 foreign import ccall unsafe "mi355lz4.h mi355lz4_compress_bound"
     c_bound :: CInt -> CInt
+-- small calls: segments per block (-1 automatic, 0 off, 2..64); include/mi355lz4.h
+foreign import ccall unsafe "mi355lz4.h mi355lz4_set_segments"
+    c_setSegments :: Ptr C_Engine -> CInt -> IO CInt
+
+-- linked device decodes without a host wait (0 = default: wait); include/mi355lz4.h
+foreign import ccall unsafe "mi355lz4.h mi355lz4_set_linked_async"
+    c_setLinkedAsync :: Ptr C_Engine -> CInt -> IO CInt
+
 foreign import ccall unsafe "mi355lz4.h mi355lz4_set_linked_compress"
     c_setLinkedCompress :: Ptr C_Engine -> CInt -> IO CInt
 
