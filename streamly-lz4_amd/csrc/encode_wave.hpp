@@ -166,6 +166,7 @@ struct SegOut {
     uint32_t count;      // records written so far (wave-uniform)
     int base;            // added to the finder's positions to make them block-relative
     bool last;           // the block's last segment: the block's end rules apply (:214-221); elsewhere a match may run up to the seam
+    int tail;            // bytes of the block behind this segment: the block's last 5 bytes are literals whichever segment they border
 };
 __device__ __forceinline__ uint64_t seg_pack(int start, int len, int off)
 {
@@ -348,7 +349,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
     if (blockLen >= 13) {                               // LZ4_minLength, :221,:921
         const int mfl = n - LZ4_MFLIMIT + 1;            // match start must be < mfl (:883)
-        const int matchlimit = (SEG && !seg->last) ? n : n - LZ4_LASTLITERALS;    // match end must be <= matchlimit (:884)
+        // match end must be <= matchlimit (:884): the BLOCK's last 5 bytes are literals; a segment with a few bytes
+        // of the block behind it stops short of its seam by what is missing
+        const int matchlimit = SEG ? n - max(0, LZ4_LASTLITERALS - seg->tail) : n - LZ4_LASTLITERALS;
         const uint32_t miss0 = (uint32_t)accel << 6;
         uint32_t missAcc = miss0;
         int64_t p = dictLen;

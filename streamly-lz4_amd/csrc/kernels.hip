@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PE
             const int dictLen = min(s0, 65536);
             so.base = s0 - dictLen;
             so.last = s1 >= n;
+            so.tail = n - s1;
             (void)encode_block_wave<uint16_t, true, true>(a.e.src + off + s0, s1 - s0, nullptr, a.e.accel, table, a.e.stats, dictLen, &so);
             count = so.count;
         }

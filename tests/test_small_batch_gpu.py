@@ -40,6 +40,20 @@ for accel in (1, 9):
     out, blen = eng.decompress_batch(fr)
     assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
     total[accel] = len(fr)
+# blocks that end a few bytes behind a seam: the BLOCK's last 5 bytes are literals whichever segment they border
+# (a match that ran up to such a seam made the reference's decoder reject the block: found by the fuzz with 33 segments)
+segs = int(os.environ.get("MI355LZ4_SEG", "0"))
+if segs >= 2:
+    seg_len = ((65536 + segs - 1) // segs + 63) & ~63
+    base = bytes(65536)
+    edge = [base] + [bytes([j %% 4]) * (seg_len * j + r) for j in (1, 2, 3) for r in range(0, 14) if seg_len * j + r <= 65536]
+    edge += [(b"abcd" * 20000)[: seg_len * j + r] for j in (1, 2) for r in (1, 3, 5, 11, 12, 13) if seg_len * j + r <= 65536]
+    fr, flen = eng.compress_batch(edge, accel=1)
+    pos = 0
+    for i, (b, f) in enumerate(zip(edge, flen)):
+        code, out = O.decompress_block(fr[pos + 8:pos + f], len(b))
+        assert code == len(b) and out == b, ("edge", i, len(b), code)
+        pos += f
 print("sizes", total[1], total[9])
 '''
 
