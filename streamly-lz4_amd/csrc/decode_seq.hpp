@@ -279,7 +279,10 @@ error:
 
 // The two out-of-line entry points.  They are plain (non-template) functions on purpose: the strict one is the
 // single non-inlined call of the lane-parallel kernel, whose occupancy is built around its register footprint.
-__device__ __attribute__((noinline)) int decode_seq_run(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+#ifndef SEQ_RUN_ATTR
+#define SEQ_RUN_ATTR __attribute__((noinline))
+#endif
+__device__ SEQ_RUN_ATTR int decode_seq_run(SeqState &st, int maxSeq, const uint8_t *src, int srcLen, uint8_t *dst, int cap,
                               const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi)
 {
     return decode_seq_body<false>(st, maxSeq, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, nullptr);
@@ -299,7 +302,10 @@ __device__ __forceinline__ int decode_seq_dispatch(SeqState &st, int maxSeq, con
 
 // Decode one whole block.  All arguments are wave-uniform.
 template <bool TOL = false>
-__device__ int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
+#ifndef SEQ_BLOCK_ATTR
+#define SEQ_BLOCK_ATTR
+#endif
+__device__ SEQ_BLOCK_ATTR int decode_block_seq(const uint8_t *src, int srcLen, uint8_t *dst, int cap,
                                 const uint8_t *dict, uint32_t dictLen, const uint8_t *bufLo,
                                 const uint8_t *bufHi, TolCtx *tol = nullptr)
 {
