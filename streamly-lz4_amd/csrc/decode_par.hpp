@@ -174,12 +174,20 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     };
 
     // ring -> global for positions [flushed, upto); 16-byte aligned stores in the body.
+    // PAR_FLUSH: granularity of a flush's body in bytes.  The body is written with 16-byte stores; what it leaves at its
+    // end is written by the NEXT flush, so a body that stops at a 16-byte boundary cuts a 32-byte sector of the L2 / HBM
+    // write path in two every time (once per ~1.5 KB batch): PMC WRITE_SIZE 4.65e6 KB per 4.29 GB of output, +11 %
+    // (round-2 review).  Stopping at 64-byte boundaries writes every sector once.
+#ifndef PAR_FLUSH
+#define PAR_FLUSH 64
+#endif
+    const uint32_t AF = (uint32_t)((uintptr_t)dst & (PAR_FLUSH - 1));
     auto flush = [&](int upto, bool final) {
         wave_fence();
         int f = flushed;
-        const int mis = (int)((A + (uint32_t)f) & 15u);
+        const int mis = (int)((AF + (uint32_t)f) & (PAR_FLUSH - 1));
         if (mis) {
-            const int head = 16 - mis;
+            const int head = PAR_FLUSH - mis;
             if (upto - f >= head) {
                 if (lane < head) dst[f + lane] = L.ring[f - ringBase + (int)A + lane];
                 f += head;
@@ -187,8 +195,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 return;
             }
         }
-        if (((A + (uint32_t)f) & 15u) == 0) {
-            const int n16 = (upto - f) >> 4;
+        if (((AF + (uint32_t)f) & (PAR_FLUSH - 1)) == 0) {
+            const int n16 = final ? (upto - f) >> 4 : ((upto - f) / PAR_FLUSH) * (PAR_FLUSH / 16);
             for (int c = lane; c < n16; c += LZ4_WAVE) {
                 const uint4 v = *(const uint4 *)&L.ring[f - ringBase + (int)A + 16 * c];
                 *(uint4 *)(dst + f + 16 * c) = v;
