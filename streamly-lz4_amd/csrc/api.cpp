@@ -596,7 +596,6 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr;
     a.asyncGate = 0;
-    a.localMode = 0; a.chaseMax = 0; a.locMeta = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -657,13 +656,12 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     const int pool = (poolMax > 0 && !walkStreams) ? ((span < poolBlocks) ? span : poolBlocks) : span;
     int seg = pool;
     if (poolMax > 0 && !walkStreams && dev_reserve(c->tolPool, (size_t)pool * per * tol_region_bytes()) == 0 &&
-        dev_reserve(c->tolMeta, ((size_t)nBlocks * 4 + 4) * sizeof(int32_t)) == 0) {
+        dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
         a.tolPool = c->tolPool.p; a.tolRegions = pool * per;
         a.tolCounter = (uint32_t *)c->tolMeta.p;
         a.tolRegion = (int32_t *)c->tolMeta.p + 4;
         a.tolCount = a.tolRegion + nBlocks;
         a.tolSize = a.tolCount + nBlocks;
-        a.locMeta = a.tolSize + nBlocks;
         const int pseg = (pool < ptrBlocks) ? pool : ptrBlocks;
         const size_t ptrs = ((size_t)pseg + 1) * per * 65536 + 65536;
         if (usePtr && ptrs < ((size_t)1 << 31) && dev_reserve(c->ptrBuf, ptrs * sizeof(uint32_t)) == 0) {
@@ -671,11 +669,6 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             a.ptrCtl = (uint8_t *)c->linkBuf.p + 64;
             a.ptrBad = (uint32_t *)((uint8_t *)c->linkBuf.p + 64 + ptr_ctl_bytes());
             seg = pseg;
-            // local resolve + chase (linked_ptr.hpp) in front of the pointer pass; MI355LZ4_LINKED_LOCAL=0: pointer
-            // pass only, MI355LZ4_LOC_CHASE=<blocks>: how far a chain is followed (the tests shrink it)
-            const char *envLocal = getenv("MI355LZ4_LINKED_LOCAL"), *envChase = getenv("MI355LZ4_LOC_CHASE");
-            a.localMode = (!envLocal || atoi(envLocal) != 0) ? 1 : 0;
-            a.chaseMax = (envChase && atoi(envChase) > 0) ? atoi(envChase) : 256;
         }
     }
     (void)hipGetLastError();          // scratch that could not be had is not an error: the serial walk needs none

@@ -46,11 +46,6 @@ struct DecodeArgs {
     void *ptrCtl;                 // PtrCtl
     uint32_t *ptrBad;             // per stream (one entry without streamFirst): left to the serial walk
     int asyncGate;                // second-pass kernels return at once when linkStat[0] == 0 (asynchronous linked decode)
-    // local resolve + chase (linked_local.hpp): the second pass of blocks of <= 64 KiB; the pointer pass above is then
-    // only run when it reports PtrCtl::needOld
-    int localMode;                // 1: local resolve + chase first, pointer pass as the fallback; 0: pointer pass only
-    int chaseMax;                 // blocks a chain is followed back through before a byte is given to the fallback
-    int32_t *locMeta;             // per block of the call: LOC_HAS_ORIGINS | size, LOC_NO_ORIGINS, or 0 (not a dependent block)
 };
 
 struct EncodeArgs {

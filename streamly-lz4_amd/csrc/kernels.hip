@@ -12,7 +12,6 @@
 #include "kernels.h"
 
 #include <algorithm>
-#include <type_traits>
 
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
@@ -756,19 +755,11 @@ __device__ __forceinline__ bool ptr_taken(const DecodeArgs &a, int blk)
     return sid >= 0 && !a.ptrBad[sid];
 }
 
-
-// The pointer pass as the fallback of local resolve + chase (linked_ptr.hpp): it only runs when that pass asked for it.
-__device__ __forceinline__ bool ptr_not_needed(const DecodeArgs &a)
-{
-    return a.localMode && __atomic_load_n(&((const PtrCtl *)a.ptrCtl)->needOld, __ATOMIC_RELAXED) == 0u;
-}
-
 // Workgroup i >= 1: block segFirst + i - 1 writes the pointers of its own bytes -- self, then its deferred
 // matches.  Workgroup 0: the bytes in front of the segment (caller's dictionary, block before the segment).
 __global__ __launch_bounds__(256) void k_ptr_expand(DecodeArgs a)
 {
     if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
-    if (ptr_not_needed(a)) return;
     uint32_t *P = a.ptr;
     const int tid = (int)threadIdx.x;
     const uint64_t lo = ptr_lo(a);
@@ -897,7 +888,6 @@ static unsigned ptr_grid(int n) { return (unsigned)((n + 8 * PTR_RUN - 1) / (8 *
 __global__ __launch_bounds__(256) void k_ptr_jump(DecodeArgs a, int pass, unsigned items)
 {
     if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
-    if (ptr_not_needed(a)) return;
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     // passes behind the first: only if the chasing fetch left something, and the pass before changed something
     if (pass > 0 && !(ctl->changed[PTR_MAX_PASSES] && ctl->changed[pass - 1])) return;
@@ -1005,7 +995,6 @@ template <bool CHASE>
 __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
 {
     if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
-    if (ptr_not_needed(a)) return;
     PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
     if (!CHASE && !ctl->changed[PTR_MAX_PASSES]) return;
     const uint32_t *P = a.ptr;
@@ -1090,378 +1079,6 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
     if (CHASE && __syncthreads_or(unresolved ? 1 : 0) && threadIdx.x == 0) ctl->changed[PTR_MAX_PASSES] = 1u;
 }
 
-
-// ---- local resolve + chase (linked_ptr.hpp, second half) ----
-// One workgroup per block of the segment.  Dependent blocks of up to 64 KiB get their origins (and the bytes whose
-// chain ends inside the block); every block gets its locMeta entry, which is what k_loc_chase goes by.
-__global__ __launch_bounds__(LOC_THREADS) void k_loc_resolve(DecodeArgs a)
-{
-    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
-    __shared__ LocLds L;
-    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int blk = a.segFirst + (int)blockIdx.x;
-    if (tid == 0) a.locMeta[blk] = 0;
-    bool hasDict = false;
-    const int sid = ptr_stream(a, blk, hasDict);
-    auto fail = [&]() { if (tid == 0 && sid >= 0) atomicOr(&a.ptrBad[sid], 1u); };
-    const int r = a.result[blk];
-    const bool listed = is_codec_error(r) && ptr_listed(a, blk);
-    if (is_codec_error(r) && !listed) { fail(); return; }          // a dependent block without a list
-    if (!listed) return;                                            // decoded on its own: every byte is final
-    const int size = a.tolSize[blk];
-    if (size > LOC_MAX) {
-        if (tid == 0) { a.locMeta[blk] = (int32_t)LOC_NO_ORIGINS; atomicOr(&ctl->needOld, 1u); }
-        return;
-    }
-    const uint64_t lo = ptr_lo(a);
-    if (a.outOff[blk] < lo) { fail(); return; }
-    const uint64_t mOff = a.outOff[blk] - lo;
-    if (mOff + (uint64_t)size > 2 * a.ptrCap) { fail(); return; }
-    // the dictionary in force (cbits/lz4.c:2347-2355 with every block in its own allocation): the block before
-    int dictLen = 0;
-    if (hasDict) {
-        const int ps = ptr_size(a, blk - 1);
-        if (ps <= 0 || a.outOff[blk - 1] < lo) { fail(); return; } // dictionary further back, or none: serial walk
-        dictLen = ps;
-    } else if (a.dict0 && !a.streamFirst) {
-        dictLen = (int)a.dict0Len;
-    }
-    const uint8_t *data = nullptr;
-    int compLen = 0, cap = 0;
-    if (read_block_header(a, blk, data, compLen, cap) != 0) { fail(); return; }
-
-    // 1. every byte its own root
-#pragma unroll
-    for (int k = 0; k < LOC_MAX / 8 / LOC_THREADS; k++) {
-        const uint32_t i0 = 8u * (uint32_t)(tid + LOC_THREADS * k);
-        const uint32_t b = i0 | ((i0 + 1u) << 16);
-        *(uint4 *)&L.lp[i0] = make_uint4(b, b + 0x00020002u, b + 0x00040004u, b + 0x00060006u);
-    }
-    for (int w = tid; w < LOC_MAX / 32; w += LOC_THREADS) L.ext[w] = 0u;
-    __syncthreads();
-
-    // 2. the deferred matches, LOC_THREADS of them at a time IN STREAM ORDER.  Byte x of a match comes from position
-    //    spos + (x - dpos) of the block, or (negative) from that far in front of it: such a byte is a root too, its ext
-    //    bit is set and lp[] holds its origin.  After a chunk's pointers are written, the bytes of the chunk's region
-    //    follow them: everything in front of the region already names its root, so a chain is over after one step
-    //    unless it passes through the chunk itself.  A root never changes, and every value a pointer ever holds is an
-    //    ancestor, so the threads need no order among themselves.
-    uint16_t *M = (uint16_t *)a.ptr + mOff;
-    uint8_t *dst = a.out + a.outOff[blk];
-    const TolEntry *list = (const TolEntry *)a.tolPool + (size_t)a.tolRegion[blk] * TOL_LIST_CAP;
-    const int n = a.tolCount[blk];
-    typedef uint2 loc_u2u __attribute__((aligned(2)));
-    auto is_ext = [&](uint32_t x) -> bool { return (L.ext[x >> 5] >> (x & 31u)) & 1u; };
-    bool bad = false, stuck = false;
-#ifdef LOC_DEBUG
-    int dbgRounds = 0, dbgHops = 0, dbgGoing = 0; long long dbgT0 = __builtin_amdgcn_s_memtime(), dbgTr = 0;
-#endif
-    for (int e0 = 0; e0 < n; e0 += LOC_THREADS) {
-        const int e = e0 + tid;
-        int gs = 0, dpos = 0, ml = 0, spos = 0;
-        if (e < n) {
-            tol_unpack(*(const uint64_t *)(list + e), dpos, ml, spos);
-            if (e > 0) {
-                int pd, pm, ps;
-                tol_unpack(*(const uint64_t *)(list + e - 1), pd, pm, ps);
-                gs = pd + pm;
-            }
-            if (!(ml >= LZ4_MINMATCH && spos < dpos && dpos + ml <= size && spos >= -dictLen && gs <= dpos)) bad = true;
-            // a match that starts in the dictionary must end LASTLITERALS before the end of the output (:1884-1889)
-            if (spos < 0 && dpos + ml > cap - LZ4_LASTLITERALS) bad = true;
-            if (bad) ml = 0;
-        }
-        if (e == e0) L.region[0] = dpos;
-        if (e == min(e0 + LOC_THREADS, n) - 1) L.region[1] = dpos + ml;
-        if (spos >= 0) {
-            // four pointers per store (ml >= 4: the last store is re-anchored at the end); what lies beyond 16 bytes
-            // is written by the whole wave
-            const int head = min(ml, 16);
-            for (int j = 0; j < head; j += 4) {
-                const int jj = min(j, head - 4);
-                const uint32_t b = (uint32_t)(spos + jj);
-                *(loc_u2u *)&L.lp[dpos + jj] = make_uint2(b | ((b + 1u) << 16), (b + 2u) | ((b + 3u) << 16));
-            }
-        } else {
-            const int head = min(ml, 16);
-            for (int j = 0; j < head; j++) {
-                const int x = dpos + j, s1 = spos + j;
-                if (s1 >= 0) { L.lp[x] = (uint16_t)s1; }
-                else { L.lp[x] = (uint16_t)(-s1); atomicOr(&L.ext[x >> 5], 1u << (x & 31)); }
-            }
-        }
-#if !defined(LOC_STOP) || LOC_STOP != 4
-        for (uint64_t lm = __ballot(ml > 16); lm; lm &= lm - 1) {
-            const int k = (int)__builtin_ctzll(lm);
-            const int kd = __builtin_amdgcn_readlane(dpos, k), ks = __builtin_amdgcn_readlane(spos, k);
-            const int kend = kd + __builtin_amdgcn_readlane(ml, k);
-            for (int x = kd + 16 + lane; x < kend; x += LZ4_WAVE) {
-                const int s1 = ks + (x - kd);
-                if (s1 >= 0) { L.lp[x] = (uint16_t)s1; }
-                else { L.lp[x] = (uint16_t)(-s1); atomicOr(&L.ext[x >> 5], 1u << (x & 31)); }
-            }
-        }
-#endif
-        __syncthreads();
-#if defined(LOC_STOP) && LOC_STOP >= 3
-        continue;
-#endif
-        const int D0 = L.region[0], D1 = L.region[1];
-        const int g0 = D0 >> 2, g1 = (D1 + 3) >> 2;
-        for (int round = 0;; round++) {
-            bool open = false;
-#ifdef LOC_DEBUG
-            dbgRounds++; const long long tr0 = __builtin_amdgcn_s_memtime();
-#endif
-            // two groups (eight bytes) per step, their hops in lock step: all sixteen LDS reads of a hop are in flight
-            // together (one workgroup per CU: there is nobody else to hide their latency)
-            for (int g = g0 + tid; g < g1; g += 2 * LOC_THREADS) {
-                const bool hasB = g + LOC_THREADS < g1;
-                const uint32_t iA = 4u * (uint32_t)g, iB = hasB ? iA + 4u * LOC_THREADS : iA;
-                const uint2 vA = *(const uint2 *)&L.lp[iA], vB = *(const uint2 *)&L.lp[iB];
-                const uint32_t ebA = (L.ext[iA >> 5] >> (iA & 31u)) & 0xfu, ebB = (L.ext[iB >> 5] >> (iB & 31u)) & 0xfu;
-                uint32_t t[8] = {vA.x & 0xffffu, vA.x >> 16, vA.y & 0xffffu, vA.y >> 16,
-                                 vB.x & 0xffffu, vB.x >> 16, vB.y & 0xffffu, vB.y >> 16};
-                uint32_t going = 0u, dirty = 0u;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t x = (i < 4 ? iA : iB) + (uint32_t)(i & 3);
-                    const uint32_t eb = i < 4 ? ebA : ebB;
-                    if ((int)x >= D0 && (int)x < D1 && !((eb >> (i & 3)) & 1u) && t[i] != x && (i < 4 || hasB)) going |= 1u << i;
-                }
-#ifdef LOC_DEBUG
-                dbgGoing += __builtin_popcount(going);
-#endif
-#pragma unroll 1
-                for (int h = 0; h < LOC_HOPS && going; h++) {
-#ifdef LOC_DEBUG
-                    dbgHops++;
-#endif
-                    uint32_t q[8], ex[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { q[i] = L.lp[t[i]]; ex[i] = L.ext[t[i] >> 5]; }
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        if (!((going >> i) & 1u)) continue;
-                        if (((ex[i] >> (t[i] & 31u)) & 1u) || q[i] == t[i]) { going &= ~(1u << i); continue; }   // t is a root
-                        if ((int)t[i] < D0) going &= ~(1u << i);                                              // q is t's root
-                        t[i] = q[i];
-                        dirty |= 1u << i;
-                    }
-                }
-                if (dirty & 0x0fu) *(uint2 *)&L.lp[iA] = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
-                if (dirty & 0xf0u) *(uint2 *)&L.lp[iB] = make_uint2(t[4] | (t[5] << 16), t[6] | (t[7] << 16));
-                if (going) open = true;
-            }
-#ifdef LOC_DEBUG
-            dbgTr += __builtin_amdgcn_s_memtime() - tr0;
-#endif
-            if (!__syncthreads_or(open ? 1 : 0)) break;
-            if (round >= 24) { stuck = true; break; }                  // cannot happen: the hops of a round multiply
-        }
-    }
-#ifdef LOC_DEBUG
-    if (blockIdx.x == 100 && (tid == 0 || tid == 517)) printf("loc dbg tid %d: n %d rounds %d hopIters %d going %d cycles(all) %lld cycles(rounds) %lld\n", tid, n, dbgRounds, dbgHops, dbgGoing, (long long)(__builtin_amdgcn_s_memtime() - dbgT0), dbgTr);
-#endif
-    // (a bad list: the stream goes to the serial walk; no output byte has been touched)
-    if (__syncthreads_or((bad || stuck) ? 1 : 0)) { fail(); return; }
-#if defined(LOC_STOP) && LOC_STOP == 2
-    return;
-#endif
-
-    // 3. what the block keeps.  A byte whose root is one of the block's own bytes is copied now (roots are final);
-    //    a byte whose root starts in the block before takes that root's origin.  The loads of four groups are in
-    //    flight together (one workgroup per CU: nobody else hides their latency).
-    const bool al = (mOff & 3u) == 0;
-#pragma unroll 1
-    for (int k4 = 0; k4 < 16; k4 += 4) {
-        uint32_t mm[4][2], fx[4], gw[4], rr[4][4], bb[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i0 = 4u * (uint32_t)(tid + LOC_THREADS * (k4 + u));
-            const uint2 v = *(const uint2 *)&L.lp[i0];
-            const uint32_t p[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
-            const uint32_t eb = (L.ext[i0 >> 5] >> (i0 & 31u)) & 0xfu;
-            uint32_t m[4] = {0u, 0u, 0u, 0u};
-            fx[u] = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i = i0 + (uint32_t)j;
-                rr[u][j] = 0u;
-                if ((int)i >= size) continue;
-                if ((eb >> j) & 1u) { m[j] = p[j]; continue; }         // its own origin
-                if (p[j] == i) continue;                                // a byte the tolerant pass wrote
-                const uint32_t r = p[j];
-                if (is_ext(r)) { m[j] = L.lp[r]; continue; }            // its root's origin
-                fx[u] |= 1u << j;                                        // its root's value
-                rr[u][j] = r;
-            }
-            mm[u][0] = m[0] | (m[1] << 16); mm[u][1] = m[2] | (m[3] << 16);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bb[u][j] = 0u;
-                if ((fx[u] >> j) & 1u) bb[u][j] = dst[rr[u][j]];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) gw[u] = bb[u][0] | (bb[u][1] << 8) | (bb[u][2] << 16) | (bb[u][3] << 24);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i0 = 4u * (uint32_t)(tid + LOC_THREADS * (k4 + u));
-            if ((int)i0 >= size) continue;
-            if (al && (int)i0 + 4 <= size) {
-                *(uint2 *)(M + i0) = make_uint2(mm[u][0], mm[u][1]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((int)i0 + j < size) M[i0 + j] = (uint16_t)(mm[u][j >> 1] >> (16 * (j & 1)));
-            }
-            if (fx[u] == 0xfu) {
-                __builtin_memcpy(dst + i0, &gw[u], 4);
-            } else if (fx[u]) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((fx[u] >> j) & 1u) dst[i0 + j] = (uint8_t)(gw[u] >> (8 * j));
-            }
-        }
-    }
-    if (tid == 0) a.locMeta[blk] = (int32_t)(LOC_HAS_ORIGINS | (uint32_t)size);
-}
-
-// Every byte with an origin is fetched from where its chain ends (PTR_PARTS workgroups per block, same map as the
-// pointer pass).  Reads only origins and final bytes; writes only bytes that have an origin, which nobody reads.
-// A hop costs ONE round trip to memory: what is known about the LOC_NEAR blocks in front of the workgroup's block is
-// kept in LDS, and the byte an origin names is requested together with that byte's own origin.
-#define LOC_NEAR 16
-struct LocNear { uint64_t off[LOC_NEAR]; int32_t size[LOC_NEAR]; uint32_t flag[LOC_NEAR]; };   // flag: LOC_HAS_ORIGINS / LOC_NO_ORIGINS / 0 = final
-
-__global__ __launch_bounds__(256) void k_loc_chase(DecodeArgs a, unsigned items)
-{
-    if (a.asyncGate && a.linkStat[0] == 0u) return;     // asynchronous linked decode: the first pass found nothing to do
-    __shared__ LocNear N;
-    PtrCtl *ctl = (PtrCtl *)a.ptrCtl;
-    const uint16_t *M = (const uint16_t *)a.ptr;
-    const uint64_t lo = ptr_lo(a);
-    const uint8_t *dictTail = (a.dict0 && !a.streamFirst) ? a.dict0 + a.dict0Len : nullptr;
-    const int hops = a.chaseMax;
-    bool gaveUp = false;
-    typedef uint2 loc_u2u __attribute__((aligned(2)));
-    typedef uint32_t loc_u32u __attribute__((aligned(1)));
-    for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
-        int blkRel, part;
-        ptr_map(item, blkRel, part);
-        const int blk = a.segFirst + blkRel;
-        if (blk >= a.segEnd || !ptr_taken(a, blk)) continue;
-        const uint32_t meta = (uint32_t)a.locMeta[blk];
-        if (!(meta & LOC_HAS_ORIGINS)) continue;
-        // (the pointer pass will redo the segment anyway once something was given up; one answer for the workgroup)
-        if (__syncthreads_or(__atomic_load_n(&ctl->needOld, __ATOMIC_RELAXED) ? 1 : 0)) break;
-        const int size = (int)(meta & 0x3fffffffu);
-        const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
-        const int x0 = part * per, x1 = min(size, x0 + per);
-        // the first block of this block's stream: nothing in front of it is a dictionary but the caller's
-        int s0 = 0;
-        if (a.streamFirst) {
-            bool hd;
-            const int sid = ptr_stream(a, blk, hd);
-            s0 = min(max(a.streamFirst[sid], 0), a.nBlocks);
-        } else if (a.lookBack > 0) {
-            s0 = -0x40000000;
-        }
-        // what a hop into block pb meets: its size, where it lies, and whether it has origins of its own
-        auto look = [&](int pb, uint64_t &po, int &ps, uint32_t &fl) {
-            const uint32_t pm = (pb >= a.segFirst) ? (uint32_t)a.locMeta[pb] : 0u;
-            fl = pm & (LOC_HAS_ORIGINS | LOC_NO_ORIGINS);
-            ps = (pm & LOC_HAS_ORIGINS) ? (int)(pm & 0x3fffffffu) : a.result[pb];
-            po = a.outOff[pb];
-        };
-        if ((int)threadIdx.x < LOC_NEAR) {                           // (the barrier above: the last item's readers are done)
-            const int pb = blk - 1 - (int)threadIdx.x;
-            uint64_t po = 0; int ps = 0; uint32_t fl = LOC_NO_ORIGINS;
-            if (pb >= s0 && pb >= a.segFirst - 1) look(pb, po, ps, fl);
-            N.off[threadIdx.x] = po; N.size[threadIdx.x] = ps; N.flag[threadIdx.x] = fl;
-        }
-        __syncthreads();
-        const uint64_t mOff = a.outOff[blk] - lo;
-        const uint16_t *Mb = M + mOff;
-        uint8_t *dst = a.out + a.outOff[blk];
-        // One hop of a chain that stands in block `cur` with origin d.  W = 1: one byte, W = 4: four bytes whose origins
-        // are d, d-1, d-2, d-3.  Returns 1 = value found, 0 = (W = 4) the four part ways, -1 = given up.
-        auto chase = [&](auto wide, int cur, uint32_t d, uint32_t &val) -> int {
-            constexpr bool W4 = decltype(wide)::value;
-#pragma unroll 1
-            for (int h = 0; h < hops; h++) {
-                if (cur <= s0) {
-                    if (!dictTail || d > a.dict0Len) return -1;
-                    if (W4) val = *(const loc_u32u *)(dictTail - (int)d); else val = dictTail[-(int)d];
-                    return 1;
-                }
-                const int pb = cur - 1, near = blk - 1 - pb;
-                uint64_t po; int ps; uint32_t fl;
-                if (near < LOC_NEAR) { po = N.off[near]; ps = N.size[near]; fl = N.flag[near]; }
-                else look(pb, po, ps, fl);
-                if (fl & LOC_NO_ORIGINS) return -1;
-                const int pos = ps - (int)d;
-                if (pos < 0) return -1;
-                const uint8_t *vp = a.out + po + (uint64_t)pos;
-                if (fl & LOC_HAS_ORIGINS) {
-                    const uint16_t *mp = M + (po - lo) + (uint64_t)pos;
-                    if (W4) {
-                        const uint2 mv = *(const loc_u2u *)mp;
-                        const uint32_t v4 = *(const loc_u32u *)vp;
-                        if (mv.x | mv.y) {
-                            const uint32_t m0 = mv.x & 0xffffu, m1 = mv.x >> 16, m2 = mv.y & 0xffffu, m3 = mv.y >> 16;
-                            if (m0 > 3u && m1 == m0 - 1u && m2 == m0 - 2u && m3 == m0 - 3u) { d = m0; cur = pb; continue; }
-                            return 0;
-                        }
-                        val = v4;
-                    } else {
-                        const uint32_t m = *mp, v1 = *vp;
-                        if (m) { d = m; cur = pb; continue; }
-                        val = v1;
-                    }
-                    return 1;
-                }
-                if (W4) val = *(const loc_u32u *)vp; else val = *vp;
-                return 1;
-            }
-            return -1;
-        };
-        auto one = [&](int x) {
-            const uint32_t m = Mb[x];
-            if (!m) return;
-            uint32_t val = 0;
-            if (chase(std::false_type{}, blk, m, val) == 1) dst[x] = (uint8_t)val; else gaveUp = true;
-        };
-        if (((mOff | (uint64_t)x0) & 3u) == 0) {
-            const int q1 = x1 >> 2;
-            for (int q = (x0 >> 2) + (int)threadIdx.x; q < q1; q += 256) {
-                const uint2 mv = *(const uint2 *)(Mb + 4 * q);
-                if (!(mv.x | mv.y)) continue;
-                const uint32_t m0 = mv.x & 0xffffu, m1 = mv.x >> 16, m2 = mv.y & 0xffffu, m3 = mv.y >> 16;
-                int st = 0;
-                uint32_t w = 0;
-                if (m0 > 3u && m1 == m0 - 1u && m2 == m0 - 2u && m3 == m0 - 3u) st = chase(std::true_type{}, blk, m0, w);
-                if (st == 1) {
-                    *(loc_u32u *)(dst + 4 * q) = w;
-                } else if (st < 0) {
-                    gaveUp = true;
-                } else {
-                    one(4 * q); one(4 * q + 1); one(4 * q + 2); one(4 * q + 3);
-                }
-            }
-            for (int x = (q1 << 2) + (int)threadIdx.x; x < x1; x += 256) one(x);
-        } else {
-            for (int x = x0 + (int)threadIdx.x; x < x1; x += 256) one(x);
-        }
-    }
-    if (__syncthreads_or(gaveUp ? 1 : 0) && threadIdx.x == 0) atomicOr(&ctl->needOld, 1u);
-}
-
 // ... and only then do the results change: the passes above tell a dependent block by its standalone result.
 __global__ __launch_bounds__(256) void k_ptr_finish(DecodeArgs a)
 {
@@ -1509,13 +1126,9 @@ void launch_linked_resolve_a(const DecodeArgs &a, hipStream_t s)
     if (a.tolPool && a.ptr && a.ptrCtl && a.ptrBad) {
         // (the stream flags follow the control block: a stream turned down in one segment gets its chance in the next)
         hipMemsetAsync(a.ptrCtl, 0, sizeof(PtrCtl) + sizeof(uint32_t) * (size_t)(a.streamFirst ? a.nStreams : 1), s);
-        if (a.localMode) {
-            hipLaunchKernelGGL(k_loc_resolve, dim3((unsigned)n), dim3(LOC_THREADS), 0, s, a);
-        } else {
-            hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
-            const unsigned items = ptr_grid(n);
-            hipLaunchKernelGGL(k_ptr_jump, dim3(items), dim3(256), 0, s, a, 0, items);
-        }
+        hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
+        const unsigned items = ptr_grid(n);
+        hipLaunchKernelGGL(k_ptr_jump, dim3(items), dim3(256), 0, s, a, 0, items);
     }
 }
 
@@ -1525,15 +1138,7 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s)
     if (n <= 0) return;
     if (a.tolPool && a.ptr && a.ptrCtl && a.ptrBad) {
         const unsigned items = ptr_grid(n), few = std::min(items, 4096u);
-        unsigned first = items;                          // grid of the first fetch (and, as the fallback, of the first jump pass)
-        if (a.localMode) {
-            hipLaunchKernelGGL(k_loc_chase, dim3(items), dim3(256), 0, s, a, items);
-            // the pointer pass, only if something was given up (kernels that return at once otherwise)
-            first = std::min(items, 16384u);
-            hipLaunchKernelGGL(k_ptr_expand, dim3((unsigned)n + 1u), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(k_ptr_jump, dim3(first), dim3(256), 0, s, a, 0, items);
-        }
-        hipLaunchKernelGGL(k_ptr_fetch<true>, dim3(first), dim3(256), 0, s, a, items);
+        hipLaunchKernelGGL(k_ptr_fetch<true>, dim3(items), dim3(256), 0, s, a, items);
         // (what follows usually finds nothing to do: small grids that stride over the items)
         for (int pass = 1; pass < PTR_MAX_PASSES; pass++)
             hipLaunchKernelGGL(k_ptr_jump, dim3(few), dim3(256), 0, s, a, pass, items);

@@ -50,34 +50,6 @@ constexpr int ptr_passes_for(int jumps)
 
 struct PtrCtl {
     uint32_t changed[PTR_MAX_PASSES + 1];   // pass r left unresolved pointers behind
-    uint32_t needOld;                       // linked_local.hpp gave something up: the pointer pass runs over the segment
-};
-
-// ---- local resolve + chase (round 3): the same second pass for blocks of up to 64 KiB, without a global pointer per byte ----
-// The tolerant pass defers practically every match of a reference-written text stream, so the pointer pass above redoes
-// the copying of the whole stream through 4-byte pointers in HBM.  Most of a chain's hops stay inside one block, though:
-//   k_loc_resolve   one workgroup per dependent block.  16-bit source pointers of the block's bytes in LDS (128 KiB:
-//                   one block per CU), pointer jumping there until every byte names its in-block root: either a byte the
-//                   tolerant pass has already written (copied now), or a byte whose match starts in the block before --
-//                   then all that is kept is WHERE in that block: its distance from the block's end (1..65535), one
-//                   uint16 per output byte ("origins", 0 = nothing to do; they live in the pointer buffer).
-//   k_loc_chase     every byte with an origin follows it: the byte it names is final (fetch it), or has an origin of its
-//                   own in the block before that one -- block by block, reads only, until a final byte turns up.  Bytes of
-//                   a match move together (consecutive origins): four at a time while they do.
-// A chain that is followed through more than DecodeArgs::chaseMax blocks, or a dependent block above 64 KiB, raises
-// PtrCtl::needOld and the pointer pass runs over the segment as before.
-#define LOC_MAX 65536
-#define LOC_THREADS 1024
-#define LOC_HAS_ORIGINS 0x80000000u
-#define LOC_NO_ORIGINS 0x40000000u
-#ifndef LOC_HOPS
-#define LOC_HOPS 4                 // pointers an item follows per round of the in-block jumping
-#endif
-
-struct __attribute__((aligned(16))) LocLds {
-    uint16_t lp[LOC_MAX];          // source of byte i: a position of the block, or (ext bit set) a distance into the block before
-    uint32_t ext[LOC_MAX / 32];    // byte i's match source lies in the block before (a root of the in-block jumping)
-    int region[2];                 // positions the chunk of deferred matches in hand covers
 };
 
 } // namespace lz4dev
