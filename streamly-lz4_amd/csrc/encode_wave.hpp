@@ -188,62 +188,62 @@ __device__ __forceinline__ uint8_t *emit_sequences(const uint8_t *src, uint8_t *
     const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
     const int incl = enc_scan_incl((int)esz);
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    uint8_t *o = op + (incl - (int)esz);
-    const uint8_t *litSrc = src + qPrev;
+    // (everything below addresses op[] and src[] through 32-bit offsets from the two wave-uniform pointers: the stores
+    // and loads then take their base from scalar registers and no 64-bit address is computed per lane)
+    uint32_t o = (uint32_t)(incl - (int)esz);
+    const uint32_t ls = (uint32_t)qPrev;
     // short literal runs: up to four 8-byte chunks per lane, all loads issued before the stores
     uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     const bool shortRun = act && lit <= 32u;
     if (shortRun && lit >= 8u) {
         const uint32_t last = lit - 8u;
-        c0 = *(const u64_unaligned *)(litSrc);
-        if (lit > 8u) c1 = *(const u64_unaligned *)(litSrc + min(8u, last));
-        if (lit > 16u) c2 = *(const u64_unaligned *)(litSrc + min(16u, last));
-        if (lit > 24u) c3 = *(const u64_unaligned *)(litSrc + last);
+        c0 = *(const u64_unaligned *)(src + ls);
+        if (lit > 8u) c1 = *(const u64_unaligned *)(src + (ls + min(8u, last)));
+        if (lit > 16u) c2 = *(const u64_unaligned *)(src + (ls + min(16u, last)));
+        if (lit > 24u) c3 = *(const u64_unaligned *)(src + (ls + last));
     } else if (shortRun && lit > 0u) {
-        c0 = *(const u64_unaligned *)(litSrc);     // the run ends at a match start, >= 12 bytes before the end of the input
+        c0 = *(const u64_unaligned *)(src + ls);     // the run ends at a match start, >= 12 bytes before the end of the input
     }
     if (act) {
-        *o++ = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
+        op[o++] = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
         if (lit >= 15u) {
             uint32_t rest = lit - 15u;
-            while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-            *o++ = (uint8_t)rest;
+            while (rest >= 255u) { op[o++] = 255; rest -= 255u; }
+            op[o++] = (uint8_t)rest;
         }
     }
-    uint8_t *litDst = o;
+    const uint32_t ld = o;
     if (shortRun) {
         if (lit >= 8u) {
             const uint32_t last = lit - 8u;
-            *(u64_unaligned *)(litDst) = c0;
-            if (lit > 8u) *(u64_unaligned *)(litDst + min(8u, last)) = c1;
-            if (lit > 16u) *(u64_unaligned *)(litDst + min(16u, last)) = c2;
-            if (lit > 24u) *(u64_unaligned *)(litDst + last) = c3;
+            *(u64_unaligned *)(op + ld) = c0;
+            if (lit > 8u) *(u64_unaligned *)(op + (ld + min(8u, last))) = c1;
+            if (lit > 16u) *(u64_unaligned *)(op + (ld + min(16u, last))) = c2;
+            if (lit > 24u) *(u64_unaligned *)(op + (ld + last)) = c3;
         } else {
             uint64_t w = c0;
             uint32_t done = 0;
-            if (lit >= 4u) { *(u32_unaligned *)litDst = (uint32_t)w; w >>= 32; done = 4; }
-            for (; done < lit; done++) { litDst[done] = (uint8_t)w; w >>= 8; }
+            if (lit >= 4u) { *(u32_unaligned *)(op + ld) = (uint32_t)w; w >>= 32; done = 4; }
+            for (; done < lit; done++) { op[ld + done] = (uint8_t)w; w >>= 8; }
         }
     }
     if (act) {
         o += lit;
-        o[0] = (uint8_t)qOff; o[1] = (uint8_t)((uint32_t)qOff >> 8);
+        op[o] = (uint8_t)qOff; op[o + 1u] = (uint8_t)((uint32_t)qOff >> 8);
         o += 2;
         if (mc >= 15u) {
             uint32_t rest = mc - 15u;
-            while (rest >= 255u) { *o++ = 255; rest -= 255u; }
-            *o++ = (uint8_t)rest;
+            while (rest >= 255u) { op[o++] = 255; rest -= 255u; }
+            op[o++] = (uint8_t)rest;
         }
     }
     // long literal runs are copied by the whole wave
     for (uint64_t lm = __ballot(act && lit > 32u); lm; lm &= lm - 1) {
         const int k = (int)__builtin_ctzll(lm);
-        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)litDst, k);
-        const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uintptr_t)litDst >> 32), k);
-        uint8_t *d = (uint8_t *)(((uintptr_t)hi32 << 32) | lo32);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)ld, k);
         const int s0 = __builtin_amdgcn_readlane(qPrev, k);
         const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
-        wave_copy_bytes(d, src + s0, ln);
+        wave_copy_bytes(op + d, src + s0, ln);
     }
     return op + total;
 }
