@@ -514,22 +514,22 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     const uint32_t lastc = ml - cs;
                     const uint32_t o0 = g16 ? min(base, lastc) : 0u;
                     const uint32_t o1 = g16 ? min(base + 16u, lastc) : lastc;
-                    // (registers of its own for every class: shared ones make the second class's reads wait for
-                    // the first class's data, one LDS round trip per class instead of one per step)
+                    // one 16-byte read serves every class (the bytes past a short match are read and dropped); the second
+                    // chunk of the short classes -- the match's last 8 / 4 bytes -- is cut out of it in registers
                     par_v4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
                     uint64_t na = 0, nc = 0;
-                    if (on && g16) {
-                        v0 = *(const par_v4u *)&L.ring[msA + o0];
-                        v1 = *(const par_v4u *)&L.ring[msA + o1];
-                    }
-                    if (on && g8) {
-                        na = *(const par_u64u *)&L.ring[msA];
-                        nc = *(const par_u64u *)&L.ring[msA + o1];
-                    }
                     uint32_t nw0 = 0, nw1 = 0;
-                    if (on && g4) {
-                        nw0 = *(const par_u32u *)&L.ring[msA];
-                        nw1 = *(const par_u32u *)&L.ring[msA + o1];
+                    if (on) v0 = *(const par_v4u *)&L.ring[msA + o0];
+                    if (on && g16 && ml > 16u) v1 = *(const par_v4u *)&L.ring[msA + o1];
+                    if (g16 && ml <= 16u) v1 = v0;                                   // (ml == 16: both chunks are the same 16 bytes)
+                    {
+                        const uint32_t sh = ml - 8u;                                     // g8: 0..7
+                        const bool up = (sh & 4u) != 0u;
+                        const uint32_t lo = up ? v0.y : v0.x, mid = up ? v0.z : v0.y, hi = up ? v0.w : v0.z;
+                        na = (uint64_t)v0.x | ((uint64_t)v0.y << 32);
+                        nc = (uint64_t)__builtin_amdgcn_alignbyte(mid, lo, sh & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(hi, mid, sh & 3u) << 32);
+                        nw0 = v0.x;
+                        nw1 = __builtin_amdgcn_alignbyte(v0.y, v0.x, (ml - 4u) & 3u);   // g4: ml - 4 = 0..3
                     }
                     if (on && g16) {
                         *(par_v4u *)&L.ring[mdA + o0] = v0;
