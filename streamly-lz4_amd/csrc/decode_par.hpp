@@ -243,7 +243,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             uint32_t J[8];
             {
                 const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
-                const uint32_t hi = (uint32_t)L.win[8 * lane + 8];
+                // the byte behind my eight is the next lane's first (wave_shl:1; lane 63 gets 0: its last node can only
+                // need that byte for a literal run of 15 or more, which ends beyond the nodes anyway)
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)lo, 0x130, 0xf, 0xf, false) & 0xffu;
                 const uint32_t nodeLim = (uint32_t)min(inLim, PAR_NODES - 1);
                 const uint32_t base3 = 8u * (uint32_t)lane + 3u;
 #pragma unroll
