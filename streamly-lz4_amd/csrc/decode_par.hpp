@@ -302,6 +302,20 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     else if (G == 2 && (g & 7)) sh = par_row_shr<2>(cj);
                     else if (G == 4 && (g & 3)) sh = par_row_shr<4>(cj);
                     else if (G == 8 && (g & 1)) sh = par_row_shr<8>(cj);
+#ifndef PAR_GROUP_BPERM
+                    // ... and across rows with the gfx950 row swaps (vector ALU) instead of a trip through the LDS crossbar:
+                    // v_permlane16_swap puts rows 0 / 2 of its source into rows 1 / 3, v_permlane32_swap rows 0-1 into rows
+                    // 2-3 (scripts/micro/permlane_swap.hip prints both); a rotation by 8 inside the row then brings the upper
+                    // half of the row below into my lanes
+                    else if (G == 8 && (g == 2 || g == 6)) {
+                        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)cj, (unsigned)cj, false, false);
+                        sh = __builtin_amdgcn_update_dpp(0, (int)r[0], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                    } else if (G == 8 && g == 4) {
+                        const auto q = __builtin_amdgcn_permlane32_swap((unsigned)cj, (unsigned)cj, false, false);
+                        const auto r = __builtin_amdgcn_permlane16_swap(q[0], q[0], false, false);
+                        sh = __builtin_amdgcn_update_dpp(0, (int)r[1], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                    }
+#endif
                     else sh = par_bperm(cj, (lane - G) & 63);
                     if (lane >= G * g && lane < G * g + G) c2 = (uint32_t)sh;
                 }
