@@ -257,6 +257,12 @@ int mi355lz4_decompress_linked_begin(mi355lz4_ctx *ctx, const uint8_t *framed, u
                                      uint8_t *out, const uint64_t *outOff, const int32_t *outCap,
                                      int32_t *result, int lookBack);
 int mi355lz4_decompress_linked_end(mi355lz4_ctx *ctx);
+/* Between _begin and _end: make the LAST block of the range final ahead of the others, so that it can go to the rank
+ * that holds the next range while this rank's own fetch is still to run (a stream over G GPUs then waits G times for
+ * one block, not for a range).  Returns 1 when result[nBlocks-1] / the block's bytes are final after this call
+ * (the call waits for them), 0 when they are not available this way -- call _end first -- or a negative
+ * MI355LZ4_E_* code.  _end must still be called.  (Reference semantics as for _begin: cbits/lz4.c:2347-2355.) */
+int mi355lz4_decompress_linked_end_last(mi355lz4_ctx *ctx);
 
 /* ---- synthetic inputs (bench / test support; SURVEY.md 8d generators) ---
  * kind: 0 = xorshift64* random, 1 = lzsynth(litMax, offMax), 2 = text-like.

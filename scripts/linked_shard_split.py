@@ -28,8 +28,21 @@ for _ in range(4):
     t = (eng.elapsed_ms(e[0], e[1]), eng.elapsed_ms(e[1], e[2]))
     best = t if best is None or sum(t) < sum(best) else best
 ok = torch.equal(out, src)
+# ... and with the range's last block made final ahead of the others (what the right neighbour waits for): wall clock,
+# the call waits for its result
+import time
+last_ms, last_ok = None, None
+for _ in range(4):
+    out.zero_()
+    eng.decompress_linked_begin(fr, len(framed), boff, NB, out, ooff, res, 0); eng.synchronize()
+    t0 = time.perf_counter(); early = eng.decompress_linked_end_last(); dt = (time.perf_counter() - t0) * 1e3
+    last_ok = bool(early) and torch.equal(out[(NB - 1) * BL:], src[(NB - 1) * BL:])
+    eng.decompress_linked_end(); eng.synchronize()
+    last_ms = dt if last_ms is None else min(last_ms, dt)
+ok = ok and torch.equal(out, src)
 e0, e1 = S.Event(), S.Event()
 eng.record(e0); eng.decompress_batch_device(fr, len(framed), boff, NB, out, ooff, res, linked=True); eng.record(e1); eng.synchronize()
 one = eng.elapsed_ms(e0, e1)
 print({"blocks": NB, "MiB": NB * BL >> 20, "begin_ms": round(best[0], 3), "end_ms": round(best[1], 3), "one_call_ms": round(one, 3),
-       "GBps_one_call": round(NB * BL / one / 1e6, 1), "serial_fraction": round(best[1] / sum(best), 3), "verified": bool(ok)})
+       "GBps_one_call": round(NB * BL / one / 1e6, 1), "serial_fraction": round(best[1] / sum(best), 3),
+       "end_last_ms": round(last_ms, 3), "end_last_final": last_ok, "verified": bool(ok)})

@@ -596,6 +596,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr;
     a.asyncGate = 0;
+    a.onlyBlk = -1;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -711,6 +712,39 @@ extern "C" int mi355lz4_decompress_linked_end(mi355lz4_ctx *c)
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     return linked_finish(c);
+}
+
+// The LAST block of a range begun with mi355lz4_decompress_linked_begin, ahead of _end: 1 = its bytes are final (the
+// caller may pass them on and call _end at leisure), 0 = not available this way (call _end first).
+extern "C" int mi355lz4_decompress_linked_end_last(mi355lz4_ctx *c)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->plan.active) return 1;                           // no block of the range needed its dictionary: all final
+    if (!c->plan.split || !c->plan.a.ptrCtl || c->plan.a.streamFirst) return 0;
+    DecodeArgs a = c->plan.a;
+    const int last = a.nBlocks - 1;
+    int r;
+    if ((r = pin_reserve(c->pinStat, 48))) return r;
+    // {lastOpen, the stream's flag, the last block's standalone result, whether it has a list}
+    uint32_t *stat = (uint32_t *)c->pinStat.p + 8;
+    uint8_t *ctl = (uint8_t *)a.ptrCtl;
+    stat[0] = stat[1] = 0; stat[3] = 0;
+    if (last >= a.segFirst && last < a.segEnd) {
+        HIP_TRY(hipMemsetAsync(ctl + ptr_ctl_last_open_offset(), 0, sizeof(uint32_t), c->stream));
+        a.onlyBlk = last;
+        launch_linked_fetch_block(a, c->stream);
+        HIP_TRY(hipMemcpyAsync(&stat[0], ctl + ptr_ctl_last_open_offset(), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&stat[1], a.ptrBad, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&stat[3], a.tolRegion + last, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(&stat[2], a.result + last, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = check_launch("decode launch"))) return r;
+    const int32_t res = (int32_t)stat[2];
+    if (res > 0) return 1;                                   // decoded on its own: final since the first pass
+    // a dependent block: final only if the pointer pass took it and its chasing fetch left nothing open
+    return (stat[0] == 0 && stat[1] == 0 && (int32_t)stat[3] >= 0) ? 1 : 0;
 }
 
 extern "C" int mi355lz4_decompress_streams_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen,

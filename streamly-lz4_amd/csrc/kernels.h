@@ -46,6 +46,7 @@ struct DecodeArgs {
     void *ptrCtl;                 // PtrCtl
     uint32_t *ptrBad;             // per stream (one entry without streamFirst): left to the serial walk
     int asyncGate;                // second-pass kernels return at once when linkStat[0] == 0 (asynchronous linked decode)
+    int onlyBlk;                  // >= 0: the fetch covers this block alone (mi355lz4_decompress_linked_end_last); -1: all
 };
 
 struct EncodeArgs {
@@ -84,6 +85,8 @@ void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s);   // both cover
 void launch_linked_resolve(const DecodeArgs &a, hipStream_t s);
 void launch_linked_resolve_a(const DecodeArgs &a, hipStream_t s);   // pointers only (no output byte is read)
 void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fetch, finish, fallbacks
+void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: the fetch of block a.onlyBlk alone; PtrCtl::lastOpen tells whether it is complete
+size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();

@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
         ptr_map(item, blkRel, part);
         const int blk = a.segFirst + blkRel;
         if (blk >= a.segEnd || !ptr_taken(a, blk)) continue;
+        if (a.onlyBlk >= 0 && blk != a.onlyBlk) continue;
         const uint32_t bLo = (uint32_t)(a.outOff[blk] - lo + PTR_PRE);
         const int size = a.tolSize[blk];
         const int per = ((size + PTR_PARTS - 1) / PTR_PARTS + 3) & ~3;
@@ -1076,7 +1077,10 @@ __global__ __launch_bounds__(256) void k_ptr_fetch(DecodeArgs a, unsigned items)
             }
         }
     }
-    if (CHASE && __syncthreads_or(unresolved ? 1 : 0) && threadIdx.x == 0) ctl->changed[PTR_MAX_PASSES] = 1u;
+    if (CHASE && __syncthreads_or(unresolved ? 1 : 0) && threadIdx.x == 0) {
+        if (a.onlyBlk >= 0) ctl->lastOpen = 1u;          // (the full fetch behind this one decides about the further passes)
+        else ctl->changed[PTR_MAX_PASSES] = 1u;
+    }
 }
 
 // ... and only then do the results change: the passes above tell a dependent block by its standalone result.
@@ -1089,6 +1093,7 @@ __global__ __launch_bounds__(256) void k_ptr_finish(DecodeArgs a)
 
 size_t tol_region_bytes() { return (size_t)TOL_LIST_CAP * sizeof(TolEntry); }
 size_t ptr_ctl_bytes() { return sizeof(PtrCtl); }
+size_t ptr_ctl_last_open_offset() { return offsetof(PtrCtl, lastOpen); }
 
 // linkStat[3] = blocks of the longest stream (the serial walk of a stream costs its length)
 __global__ __launch_bounds__(256) void k_longest_stream(DecodeArgs a)
@@ -1151,6 +1156,17 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s)
                            dim3(RPL_THREADS), 0, s, a);
     else if (a.nStreams > 0)
         hipLaunchKernelGGL(k_decode_fixup_linked, dim3((unsigned)a.nStreams), dim3(64), 0, s, a);
+}
+
+// One block of the segment fetched ahead of the others (a.onlyBlk): what a rank hands to its right neighbour when ONE
+// linked stream is spread over several GPUs -- the neighbour then waits for one block's fetch, not for a range's.  The
+// chasing fetch is complete unless it raises PtrCtl::lastOpen (a chain deeper than the first jump pass plus PTR_CHASE).
+void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0 || !(a.tolPool && a.ptr && a.ptrCtl && a.ptrBad)) return;
+    const unsigned items = ptr_grid(n);
+    hipLaunchKernelGGL(k_ptr_fetch<true>, dim3(std::min(items, 4096u)), dim3(256), 0, s, a, items);
 }
 
 void launch_linked_resolve(const DecodeArgs &a, hipStream_t s)

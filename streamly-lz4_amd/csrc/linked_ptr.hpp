@@ -50,6 +50,7 @@ constexpr int ptr_passes_for(int jumps)
 
 struct PtrCtl {
     uint32_t changed[PTR_MAX_PASSES + 1];   // pass r left unresolved pointers behind
+    uint32_t lastOpen;                      // the fetch of one block alone (DecodeArgs::onlyBlk) left bytes of it unresolved
 };
 
 } // namespace lz4dev

@@ -93,6 +93,7 @@ def _load():
     sig("mi355lz4_decompress_linked_begin", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
         C.c_int)
     sig("mi355lz4_decompress_linked_end", C.c_int, vp)
+    sig("mi355lz4_decompress_linked_end_last", C.c_int, vp)
     sig("mi355lz4_index_device", C.c_int, vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp)
     sig("mi355lz4_compress_batch", C.c_int, vp, C.POINTER(_u8p), _i32p, C.c_int, C.c_int, C.c_int, _u8p,
         C.c_size_t, C.POINTER(C.c_size_t), _i32p, _i32p)
@@ -150,7 +151,7 @@ DECLARED_SYMBOLS = [
     "mi355lz4_set_stream", "mi355lz4_get_stream", "mi355lz4_synchronize", "mi355lz4_set_decoder", "mi355lz4_set_segments", "mi355lz4_set_linked_async", "mi355lz4_set_linked_compress",
     "mi355lz4_compress_bound", "mi355lz4_slot_stride", "mi355lz4_compress_batch_device", "mi355lz4_compact_device",
     "mi355lz4_decompress_batch_device", "mi355lz4_decompress_streams_device", "mi355lz4_decompress_linked_begin",
-    "mi355lz4_decompress_linked_end", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
+    "mi355lz4_decompress_linked_end", "mi355lz4_decompress_linked_end_last", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
     "mi355lz4_decompress_batch", "mi355lz4_decompress_streams", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
     "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
     "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
@@ -371,6 +372,16 @@ class Engine:
             self.ctx, _dptr(framed), int(framed_len), _dptr(block_off), int(n_blocks), int(header_kind), int(fixed_uncomp),
             _dptr(out), C.c_void_p(out_off.data_ptr() + 8 * lb), None, C.c_void_p(result.data_ptr() + 4 * lb), lb),
             "decompress_linked_begin")
+
+    def decompress_linked_end_last(self):
+        """Between begin and end: make the range's LAST block final ahead of the rest.  True: its bytes and result are
+        final (hand them on, call decompress_linked_end afterwards); False: not available this way, call
+        decompress_linked_end first."""
+        self._follow_torch()
+        r = lib.mi355lz4_decompress_linked_end_last(self.ctx)
+        if r < 0:
+            _check(r, "decompress_linked_end_last")
+        return r == 1
 
     def decompress_linked_end(self):
         """Second half: fetch from the roots (the first of which lie in the look-back block's output), results."""

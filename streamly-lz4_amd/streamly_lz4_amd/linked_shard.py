@@ -18,12 +18,14 @@ import torch
 import torch.distributed as dist
 
 
-def decode_linked_sharded(engine, framed, framed_len, block_off, ulen, group=None, header_kind=8, fixed_uncomp=0):
+def decode_linked_sharded(engine, framed, framed_len, block_off, ulen, group=None, header_kind=8, fixed_uncomp=0,
+                          use_end_last=True):
     """This rank's contiguous range of ONE linked stream.
 
     framed     uint8 device tensor: the range's framed blocks, dense
     block_off  int64 device tensor (n + 1): offsets of the block headers in `framed`
     ulen       int64 host tensor / list (n): decoded size of each block (the header's uncompLen, or the capacity)
+    use_end_last  hand the range's last block on before the rest of the range is fetched (False: after, for the tests)
     Returns (out, result): the range's decoded bytes (blocks back to back) and the per-block results (int32)."""
     rank = dist.get_rank(group)
     G = dist.get_world_size(group)
@@ -63,8 +65,7 @@ def decode_linked_sharded(engine, framed, framed_len, block_off, ulen, group=Non
         out[:seam].copy_(stage, non_blocking=False)
         if getattr(engine, "_pinned", False):
             torch.cuda.current_stream(dev).synchronize()
-    engine.decompress_linked_end()
-    if rank + 1 < G and n > 0:
+    def send_last():
         if getattr(engine, "_pinned", False):
             engine.synchronize()
         last = out[int(out_off[n].item()): int(out_off[n + 1].item())]
@@ -73,5 +74,16 @@ def decode_linked_sharded(engine, framed, framed_len, block_off, ulen, group=Non
             dist.send(last.cpu(), dst=rank + 1, group=group)
         else:
             dist.send(last.contiguous(), dst=rank + 1, group=group)
+
+    # The right neighbour waits for ONE block: the range's last block is fetched ahead of the others and sent on, the
+    # rest of the range is fetched while the neighbours further right take their turn.  (When that block is not
+    # available ahead -- a chain deeper than the chasing fetch follows, a range in several segments -- the whole range
+    # is finished first, as before.)
+    early = rank + 1 < G and n > 0 and use_end_last and engine.decompress_linked_end_last()
+    if early:
+        send_last()
+    engine.decompress_linked_end()
+    if rank + 1 < G and n > 0 and not early:
+        send_last()
     engine.synchronize()
     return out[seam:total], result[1:]

@@ -39,7 +39,7 @@ def _stream(oracle, kind, n_blocks, seed):
     return raw, framed, offs
 
 
-def _worker(rank, world, port, kind, n_blocks, cuts, q):
+def _worker(rank, world, port, kind, n_blocks, cuts, q, early=True):
     for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -57,7 +57,7 @@ def _worker(rank, world, port, kind, n_blocks, cuts, q):
         mine = framed[offs[b0]:offs[b1]]
         fr = torch.from_numpy(np.frombuffer(mine, dtype=np.uint8).copy()).cuda()
         boff = torch.tensor([o - offs[b0] for o in offs[b0:b1 + 1]], dtype=torch.int64).cuda()
-        out, res = decode_linked_sharded(eng, fr, len(mine), boff, [BL] * (b1 - b0))
+        out, res = decode_linked_sharded(eng, fr, len(mine), boff, [BL] * (b1 - b0), use_end_last=early)
         ok = res.cpu().tolist() == [BL] * (b1 - b0) and out.cpu().numpy().tobytes() == raw[b0 * BL:b1 * BL]
         q.put((rank, bool(ok)))
         eng.close()
@@ -65,14 +65,16 @@ def _worker(rank, world, port, kind, n_blocks, cuts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,n_blocks,cuts", [("text", 48, [0, 20, 48]), ("shared", 40, [0, 1, 40]),
-                                                ("text", 96, [0, 30, 61, 96]), ("lzsynth", 16, [0, 8, 16])])
-def test_one_linked_stream_over_ranks(kind, n_blocks, cuts):
+@pytest.mark.parametrize("kind,n_blocks,cuts,early", [("text", 48, [0, 20, 48], True), ("shared", 40, [0, 1, 40], True),
+                                                      ("text", 96, [0, 30, 61, 96], True), ("lzsynth", 16, [0, 8, 16], True),
+                                                      ("text", 56, [0, 30, 56], False)])
+def test_one_linked_stream_over_ranks(kind, n_blocks, cuts, early):
+    """early: a rank hands its last block on before the rest of its range is fetched (mi355lz4_decompress_linked_end_last)."""
     world = len(cuts) - 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29710 + n_blocks + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_blocks, cuts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_blocks, cuts, q, early)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -111,7 +113,13 @@ def test_begin_end_equals_one_call(engine, oracle):
     res3[0] = BL
     engine.decompress_linked_begin(fr3, len(sub), boff3, m, out3, ooff3, res3, 1)
     out3[:BL].copy_(out1[(b0 - 1) * BL: b0 * BL])                           # the seam arrives
+    # the range's last block ahead of the others: final before _end has run
+    assert engine.decompress_linked_end_last() is True
+    assert out3[m * BL:].cpu().numpy().tobytes() == raw[(n - 1) * BL:]
+    assert not torch.equal(out3[BL:], out1[b0 * BL:])                       # (the rest of the range is not there yet)
     engine.decompress_linked_end()
     engine.synchronize()
     assert res3.cpu().tolist() == [BL] * (m + 1)
     assert out3[BL:].cpu().numpy().tobytes() == raw[b0 * BL:]
+    # nothing begun, or a range in which no block needs its dictionary: the last block is final as it is
+    assert engine.decompress_linked_end_last() is True
