@@ -141,6 +141,78 @@ def host_api_rates(S, eng, src, BL, kind):
     return res
 
 
+def one_stream_bench(args, torch, S, dist, eng, dev, rank, world, red_dev, kind, BL, NB, accel):
+    """ONE linked stream over all ranks: rank r holds blocks [r NB, (r + 1) NB) of the generator's
+    stream, compressed as one linked stream (block k's dictionary is block k - 1, across the ranks' seams too), and
+    decodes its range with linked_shard.decode_linked_sharded.  Prints one JSON line (rank 0)."""
+    from streamly_lz4_amd.linked_shard import decode_linked_sharded
+    lb = 1 if rank > 0 else 0                           # the block in front of my range: my first block's dictionary
+    n = NB + lb
+    src = torch.empty(n * BL, dtype=torch.uint8, device=dev)
+    eng.generate(kind, src, BL, n, first_block=rank * NB - lb, block_step=1)
+    stride = S.slot_stride(BL, 8)
+    slots = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    flen = torch.empty(n, dtype=torch.int32, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    dense = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    eng.set_linked_compress(True)
+    eng.compress_batch_device(src, n, BL, slots, stride, flen, accel=accel)
+    eng.compact_device(slots, stride, flen, n, dense, n * stride, doff)
+    eng.synchronize()
+    # my range's framed blocks: everything behind the look-back block (which only served as the dictionary)
+    first = int(doff[lb].item())
+    total = int(doff[-1].item())
+    framed = dense[first:total]
+    boff = (doff[lb:] - first).contiguous()
+    mine = src[lb * BL:]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if dist is None:
+            ooff = torch.arange(NB + 1, dtype=torch.int64, device=dev) * BL
+            out = torch.empty(NB * BL, dtype=torch.uint8, device=dev)
+            res = torch.empty(NB, dtype=torch.int32, device=dev)
+            eng.decompress_batch_device(framed, total - first, boff, NB, out, ooff, res, linked=True)
+            eng.synchronize()
+            return out, res
+        return decode_linked_sharded(eng, framed, total - first, boff, [BL] * NB)
+
+    out, res = step()
+    if not (bool((res == BL).all().item()) and torch.equal(out, mine)):
+        sys.exit("bench.py --one-stream: rank %d's range does not decode to the generator's blocks" % rank)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cb = torch.tensor([float(total - first)], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cb, op=dist.ReduceOp.SUM)
+        elapsed = float(tt.item())
+    if rank == 0:
+        U = NB * BL
+        print(json.dumps({
+            "metric": "GB/s uncompressed, ONE linked stream decoded by all ranks (not the headline metric)",
+            "value": round(world * U / (elapsed / max(args.steps, 1)) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "one-stream: %s, %d KiB blocks, contiguous ranges of %d blocks per rank, ONE linked stream "
+                                   "of %d blocks written by the engine's linked compression, seam block passed rank to rank"
+                                   % (kind, BL >> 10, NB, NB * world),
+                       "ratio": round(world * U / float(cb.item()), 4), "verified": True}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +225,10 @@ def main():
     ap.add_argument("--linked-compress", action="store_true",
                     help="compress this rank's blocks as ONE linked stream (previous block = dictionary, like the "
                          "reference's compressor) and decode it with linked = 1")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="the ranks' blocks are contiguous ranges of ONE linked stream (written by the engine's linked "
+                         "compression), decoded range by range with the seam block passed from rank to rank "
+                         "(streamly_lz4_amd/linked_shard.py); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the multi-threaded best-case CPU figure")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0)
@@ -192,6 +268,9 @@ def main():
         NB = args.blocks
     eng = S.Engine(dev_index)
     eng.set_decoder(args.decoder)
+    if args.one_stream:
+        one_stream_bench(args, torch, S, dist, eng, dev, rank, world, red_dev, kind, BL, NB, accel)
+        return
     if args.linked_compress:
         eng.set_linked_compress(True)
         args.linked = True

@@ -21,6 +21,11 @@ python3 scripts/small_enc_latency.py 2>/dev/null | grep -v amdgpu > "$E/small_ba
 python3 scripts/small_dec_breakdown.py 2>/dev/null | grep accel > "$E/small_call_decompress_breakdown.txt"
 python3 scripts/linked_shard_split.py 4096 2>/dev/null | tail -1 > "$E/linked_shard_split.txt"
 python3 scripts/linked_shard_split.py 1024 2>/dev/null | tail -1 >> "$E/linked_shard_split.txt"
+python3 bench.py --one-stream --workload text --steps 5 --warmup 1 --blocks 4096 > "$E/bench_one_stream_rehearsal.jsonl" 2>/dev/null
+for N in 2 3; do
+  BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2955$N \
+      bench.py --gpus $N --steps 5 --warmup 1 --workload text --one-stream --blocks 2048 2>/dev/null | grep '^{' >> "$E/bench_one_stream_rehearsal.jsonl"
+done
 python3 scripts/linked_async_cost.py 2>/dev/null | grep blocks > "$E/linked_async_cost.txt"
 python3 scripts/realtext_ratio.py 2>/dev/null | grep input > "$E/realtext_ratio.txt"
 python3 scripts/size_vs_ref.py 2>/dev/null | grep segs > "$E/size_vs_reference.txt"
