@@ -253,9 +253,12 @@ static uint32_t common_len(const uint8_t *a, const uint8_t *b, const uint8_t *li
 void orc_cstream_init(orc_cstream *s) { memset(s, 0, sizeof(*s)); }
 
 /* cbits/lz4.c:1545-1562 */
+static long g_renorms;                       /* how often the rebase below has run (tests/test_oracle_renorm.py) */
+long orc_debug_renorms(void) { return g_renorms; }
 static void renorm(orc_cstream *s, int nextSize)
 {
     if (s->currentOffset + (uint32_t)nextSize > 0x80000000u) {
+        g_renorms++;
         uint32_t delta = s->currentOffset - 65536u;
         const uint8_t *dictEnd = s->dict + s->dictSize;
         int i;
