@@ -12,6 +12,7 @@ bash scripts/profile_bench.sh dec > "$E/profile_dec.log" 2>&1
 bash scripts/profile_bench.sh cmp --workload compress > "$E/profile_cmp.log" 2>&1
 bash scripts/profile_bench.sh text --workload text > "$E/profile_text.log" 2>&1
 for k in lzsynth text; do bash scripts/pmc_encode.sh $k > "$E/encode_${k}_pmc_instmix.txt" 2>&1; done
+for k in lzsynth text; do bash scripts/pmc_decode.sh $k > "$E/decode_${k}_pmc_instmix.txt" 2>&1; done
 python3 bench.py --workload roundtrip --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_roundtrip.json" 2> "$E/bench_roundtrip.err"
 python3 bench.py --workload random256k --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_random256k.json" 2> "$E/bench_random256k.err"
 python3 bench.py --workload text --steps 20 --warmup 2 --linked-compress --no-cpu-baseline > "$E/bench_text_linked_compress.json" 2> "$E/bench_text_linked_compress.err"
