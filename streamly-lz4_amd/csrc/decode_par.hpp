@@ -56,7 +56,8 @@ namespace lz4dev {
 #endif
 
 // jump[] is the successor table of step 3.  Entries are BYTE offsets into jump[] itself (2 x node
-// index), so a gather is one ds_read_u16 with no address arithmetic; 2*PAR_NODES is the absorbing state.
+// index), so a gather is one ds_read_u16 with no address arithmetic.  The absorbing state of a batch is the node behind
+// the last one that may hold a token (`absorb` in the speculative parse), at most 2*PAR_NODES: the entry behind the table.
 struct __attribute__((aligned(16))) ParLds {
     uint8_t win[PAR_WIN + 32];
     uint16_t jump[PAR_NODES + 8];
@@ -241,32 +242,43 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
             // ---------------- 2. speculative parse (registers only) ----------------
             uint32_t J[8];
+            // Two nodes per instruction (16-bit halves, v_pk_*).  The absorbing state is the node behind the last one that
+            // may be a token, nodeLim + 1: every successor beyond nodeLim is clamped to it, its own included (a successor
+            // lies at least three bytes on), so no comparison is needed; for nodeLim = PAR_NODES - 1 that is the extra
+            // entry behind the table.
+            const uint32_t absorb = 2u * ((uint32_t)min(inLim, PAR_NODES - 1) + 1u);
             {
+                typedef unsigned short par_h2 __attribute__((ext_vector_type(2)));
                 const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
-                // the byte behind my eight is the next lane's first (wave_shl:1; lane 63 gets 0: its last node can only
-                // need that byte for a literal run of 15 or more, which ends beyond the nodes anyway)
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)lo, 0x130, 0xf, 0xf, false) & 0xffu;
-                const uint32_t nodeLim = (uint32_t)min(inLim, PAR_NODES - 1);
-                const uint32_t base3 = 8u * (uint32_t)lane + 3u;
+                const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xf, 0xf, false);   // next lane's first bytes
+                auto h2 = [](uint32_t x) { par_h2 r; __builtin_memcpy(&r, &x, 4); return r; };
+                auto u32 = [](par_h2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; };
+                const par_h2 one = {1, 1}, lim = h2((absorb >> 1) * 0x00010001u);
+                const uint32_t base3 = (8u * (uint32_t)lane + 3u) * 0x00010001u + 0x00010000u;   // nodes 2p, 2p + 1 of pair p: + 2p
+                uint32_t P[4];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t t = (uint32_t)(lo >> (8 * j)) & 0xffu;
-                    const uint32_t b1 = (j < 7) ? ((uint32_t)(lo >> (8 * (j + 1))) & 0xffu) : hi;
-                    const uint32_t lit0 = t >> 4;
-                    // token + literals + 2 offset bytes (+1 literal-length byte, +1 match-length byte);
-                    // 255-valued length bytes are caught when the real token is decoded (step 4)
-                    uint32_t nxt = base3 + (uint32_t)j + ((lit0 == 15u) ? 16u + b1 : lit0);
-                    nxt += ((t & 15u) == 15u) ? 1u : 0u;
-                    J[j] = ((int)nxt <= (int)nodeLim) ? 2u * nxt : (uint32_t)PAR_END;
+                for (int p = 0; p < 4; p++) {
+                    // tokens of the two nodes and the byte behind each, zero-extended into the halves
+                    const uint32_t ws = (p < 2) ? w0 : w1, wn = (p < 2) ? w1 : w2;
+                    const par_h2 T = h2(__builtin_amdgcn_perm(0u, ws, (p & 1) ? 0x0c030c02u : 0x0c010c00u));
+                    const par_h2 B = h2((p & 1) ? __builtin_amdgcn_perm(wn, ws, 0x0c040c03u) : __builtin_amdgcn_perm(0u, ws, 0x0c020c01u));
+                    const par_h2 lit0 = T >> 4;
+                    const par_h2 ext = (lit0 + one) >> 4;                       // 1 when the literal nibble is 15
+                    const par_h2 term = ext * (B + one) + lit0;                 // 15 + 1 + b1, or the nibble
+                    const par_h2 mlx = ((T & (par_h2){15, 15}) + one) >> 4;     // 1 when the match nibble is 15
+                    const par_h2 nxt = term + mlx + h2(base3 + 0x00020002u * (uint32_t)p);
+                    P[p] = u32(__builtin_elementwise_min(nxt, lim) << 1);
                 }
-                *(uint4 *)&L.jump[8 * lane] =
-                    make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
+                *(uint4 *)&L.jump[8 * lane] = make_uint4(P[0], P[1], P[2], P[3]);
+#pragma unroll
+                for (int p = 0; p < 4; p++) { J[2 * p] = P[p] & 0xffffu; J[2 * p + 1] = P[p] >> 16; }
             }
             wave_fence();
             lap(PS_T_SPEC);
 
             // ---------------- 3. chain: sequence r -> lane r ----------------
-            uint32_t c2 = (lane == 0) ? 2u * (uint32_t)wofs : (uint32_t)PAR_END;   // 2 x token position
+            uint32_t c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
             // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
             // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
             // one 8-lane gather per group instead of two more squarings of all 512 nodes.
@@ -294,7 +306,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 constexpr int G = 1 << PAR_SQ;
 #pragma unroll
                 for (int g = 1; g < LZ4_WAVE / G; g++) {
-                    int cj = PAR_END;
+                    int cj = (int)absorb;
                     if (lane >= G * (g - 1) && lane < G * g) cj = (int)*(const uint16_t *)(jumpB + c2);
                     int sh;
                     // the next group sits G lanes up: a DPP row shift while that stays inside a row of 16 lanes
@@ -323,7 +335,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             lap(PS_T_CHAIN);
 
             // ---------------- 4. decode own sequence, place it ----------------
-            const bool has = c2 < (uint32_t)PAR_END;
+            const bool has = c2 < absorb;
             const uint32_t cc = has ? (c2 >> 1) : 0u;
             const uint32_t tb = lds_u32_any(L.win, cc);                          // token, next byte
             const uint32_t t = tb & 0xffu, b1 = (tb >> 8) & 0xffu;
