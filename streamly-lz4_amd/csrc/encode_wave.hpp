@@ -185,14 +185,8 @@ __device__ __forceinline__ uint8_t *emit_sequences(const uint8_t *src, uint8_t *
     const bool act = lane < qCnt;
     const uint32_t lit = act ? (uint32_t)(qStart - qPrev) : 0u;
     const uint32_t mc = act ? (uint32_t)(qLen - LZ4_MINMATCH) : 0u;
-    const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
-    const int incl = enc_scan_incl((int)esz);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    // (everything below addresses op[] and src[] through 32-bit offsets from the two wave-uniform pointers: the stores
-    // and loads then take their base from scalar registers and no 64-bit address is computed per lane)
-    uint32_t o = (uint32_t)(incl - (int)esz);
     const uint32_t ls = (uint32_t)qPrev;
-    // short literal runs: up to four 8-byte chunks per lane, all loads issued before the stores
+    // short literal runs: up to four 8-byte chunks per lane, requested first (they only need the queue's positions)
     uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     const bool shortRun = act && lit <= 32u;
     if (shortRun && lit >= 8u) {
@@ -204,15 +198,19 @@ __device__ __forceinline__ uint8_t *emit_sequences(const uint8_t *src, uint8_t *
     } else if (shortRun && lit > 0u) {
         c0 = *(const u64_unaligned *)(src + ls);     // the run ends at a match start, >= 12 bytes before the end of the input
     }
-    if (act) {
-        op[o++] = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
-        if (lit >= 15u) {
-            uint32_t rest = lit - 15u;
-            while (rest >= 255u) { op[o++] = 255; rest -= 255u; }
-            op[o++] = (uint8_t)rest;
-        }
-    }
+    const uint32_t esz = act ? 1u + lit + ext_len_bytes(lit) + 2u + ext_len_bytes(mc) : 0u;
+    const int incl = enc_scan_incl((int)esz);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    // (everything below addresses op[] and src[] through 32-bit offsets from the two wave-uniform pointers: the stores
+    // and loads then take their base from scalar registers and no 64-bit address is computed per lane)
+    uint32_t o = (uint32_t)(incl - (int)esz);
+    // Every store of the sequence is issued behind the one wait for the literal loads above: the vector memory counter
+    // counts loads and stores together, so a store in front of that wait would have to be acknowledged before the
+    // literals could move (one trip to memory and back per emission for each such place).
+    const uint32_t tok = o;                                    // token, then the literal length's extra bytes
+    o += 1u + ext_len_bytes(lit);
     const uint32_t ld = o;
+    __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0): the literals are here; nothing below waits again
     if (shortRun) {
         if (lit >= 8u) {
             const uint32_t last = lit - 8u;
@@ -228,6 +226,13 @@ __device__ __forceinline__ uint8_t *emit_sequences(const uint8_t *src, uint8_t *
         }
     }
     if (act) {
+        uint32_t t = tok;
+        op[t++] = (uint8_t)((min(lit, 15u) << 4) | min(mc, 15u));
+        if (lit >= 15u) {
+            uint32_t rest = lit - 15u;
+            while (rest >= 255u) { op[t++] = 255; rest -= 255u; }
+            op[t++] = (uint8_t)rest;
+        }
         o += lit;
         op[o] = (uint8_t)qOff; op[o + 1u] = (uint8_t)((uint32_t)qOff >> 8);
         o += 2;
