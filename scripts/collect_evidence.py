@@ -15,7 +15,7 @@ names = {"bench_roundtrip.json": "bench_roundtrip.json", "bench_random256k.json"
          "encode_text_pmc_instmix.txt": "encode_text_pmc_instmix.txt", "decode_lzsynth_pmc_instmix.txt": "decode_lzsynth_pmc_instmix.txt",
          "decode_text_pmc_instmix.txt": "decode_text_pmc_instmix.txt", "small_batch_compress_latency.txt": "small_batch_compress_latency.txt",
          "small_call_decompress_breakdown.txt": "small_call_decompress_breakdown.txt", "linked_shard_split.txt": "linked_shard_split.txt",
-         "linked_async_cost.txt": "linked_async_cost.txt", "bench_one_stream_rehearsal.jsonl": "bench_one_stream_rehearsal.jsonl", "realtext_ratio.txt": "realtext_ratio.txt", "size_vs_reference.txt": "size_vs_reference.txt",
+         "linked_async_cost.txt": "linked_async_cost.txt", "linked_single_stream_kernel_stats.csv": "linked_single_stream_kernel_stats.csv", "bench_one_stream_rehearsal.jsonl": "bench_one_stream_rehearsal.jsonl", "realtext_ratio.txt": "realtext_ratio.txt", "size_vs_reference.txt": "size_vs_reference.txt",
          "host_api_rate.jsonl": "host_api_rate.jsonl", "linked_streams_rate.jsonl": "linked_streams_rate.jsonl", "kernel_resources.txt": "kernel_resources.txt"}
 files = []
 for src, dst in names.items():

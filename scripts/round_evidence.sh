@@ -27,6 +27,7 @@ for N in 2 3; do
   BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2955$N \
       bench.py --gpus $N --steps 5 --warmup 1 --workload text --one-stream --blocks 2048 2>/dev/null | grep '^{' >> "$E/bench_one_stream_rehearsal.jsonl"
 done
+( cd /tmp && export TMPDIR=/tmp && rm -rf "$E/linked_prof" && rocprofv3 --kernel-trace --stats --output-format csv -d "$E/linked_prof" -- python3 "$R/scripts/prof_linked.py" 4096 5 > "$E/linked_prof.log" 2>&1; cp "$E"/linked_prof/*/*kernel_stats.csv "$E/linked_single_stream_kernel_stats.csv" 2>/dev/null )
 python3 scripts/linked_async_cost.py 2>/dev/null | grep blocks > "$E/linked_async_cost.txt"
 python3 scripts/realtext_ratio.py 2>/dev/null | grep input > "$E/realtext_ratio.txt"
 python3 scripts/size_vs_ref.py 2>/dev/null | grep segs > "$E/size_vs_reference.txt"
