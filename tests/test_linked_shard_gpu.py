@@ -39,12 +39,13 @@ def _stream(oracle, kind, n_blocks, seed):
     return raw, framed, offs
 
 
-def _worker(rank, world, port, kind, n_blocks, cuts, q, early=True):
+def _worker(rank, world, port, kind, n_blocks, cuts, q, early=True, env=None):
     for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.update(env or {})
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import streamly_lz4_amd as S
@@ -67,14 +68,19 @@ def _worker(rank, world, port, kind, n_blocks, cuts, q, early=True):
 
 @pytest.mark.parametrize("kind,n_blocks,cuts,early", [("text", 48, [0, 20, 48], True), ("shared", 40, [0, 1, 40], True),
                                                       ("text", 96, [0, 30, 61, 96], True), ("lzsynth", 16, [0, 8, 16], True),
-                                                      ("text", 56, [0, 30, 56], False)])
+                                                      ("text", 56, [0, 30, 56], False),
+                                                      ("text", 44, [0, 21, 44], "segments")])
 def test_one_linked_stream_over_ranks(kind, n_blocks, cuts, early):
-    """early: a rank hands its last block on before the rest of its range is fetched (mi355lz4_decompress_linked_end_last)."""
+    """early: a rank hands its last block on before the rest of its range is fetched (mi355lz4_decompress_linked_end_last);
+    "segments": the pointer pass is given 8 blocks at a time, so a range is several segments, the last block is not
+    available ahead and the call must say so (the driver then finishes the range first)."""
+    env = {"MI355LZ4_LINKED_PTR_BLOCKS": "8"} if early == "segments" else None
+    early = bool(early)
     world = len(cuts) - 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29710 + n_blocks + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_blocks, cuts, q, early)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_blocks, cuts, q, early, env)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
