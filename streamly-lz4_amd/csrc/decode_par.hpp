@@ -46,10 +46,16 @@ namespace lz4dev {
 #define PAR_RING 6144       // LDS output staging (8.3 KiB of LDS per wave in all: 19 waves per CU)
 #endif
 #ifndef PAR_HIST
-#define PAR_HIST 2048       // bytes of history kept in the ring across a slide
+#define PAR_HIST 2000       // bytes of history kept in the ring across a slide: two 16-byte chunks per lane (2048 needed a third pass for one or two chunks)
 #endif
 #ifndef PAR_BATCH_OUT
 #define PAR_BATCH_OUT 2560  // max output bytes of one batch
+#endif
+#ifndef PAR_FAR_WIDE
+#define PAR_FAR_WIDE 1      // far matches: one 16-byte request per lane instead of two requests per length class
+#endif
+#ifndef PAR_RANK
+#define PAR_RANK 1          // dependency masks from a bit vector of sequence starts (rank queries) instead of binary searches
 #endif
 #ifndef PAR_WAVES
 #define PAR_WAVES 5         // occupancy target (waves per SIMD) the register allocator is held to (<= 102 VGPRs)
@@ -357,7 +363,8 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const int spos = dpos - (int)off16;              // match source
             ok = ok && incl <= PAR_BATCH_OUT && outEnd + 64 < cap &&
                  ((spos >= 0 && (spos >= ringBase || spos + (int)ml <= flushed)) ||
-                  (DICT && spos >= dictLo && spos + (int)ml <= 0) || (TOL && spos < 0));
+                  (DICT && spos >= dictLo && spos + (int)ml <= 0 && (!PAR_FAR_WIDE || ml >= 16u || spos + 16 <= 0)) ||
+                  (TOL && spos < 0));
             const uint64_t okm = __ballot(ok);
             const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
             lap(PS_T_DECODE);
@@ -404,6 +411,14 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             uint32_t fw0 = 0, fw1 = 0;
             if (farm) {
                 if (STATS) sc[PS_FAR] += (unsigned)__builtin_popcountll(farm);
+#if PAR_FAR_WIDE
+                // ONE 16-byte request per lane whatever the length (a second one, re-anchored at the end, above 16 bytes);
+                // the short classes' second chunk is cut out of it in registers like the near matches' below.  The request
+                // never leaves the output buffer (cap - op >= 128), and a dictionary match shorter than 16 bytes is only
+                // taken when 16 bytes are left in the dictionary (`ok` above).
+                if (farMine) __builtin_memcpy(&f0, gsrc, 16);
+                if (farMine && fstep == 16 && ml > 16u) __builtin_memcpy(&f1, gsrc + min(16u, flast), 16);
+#else
                 if (farMine && fstep == 16) {
                     __builtin_memcpy(&f0, gsrc, 16);
                     __builtin_memcpy(&f1, gsrc + min(16u, flast), 16);
@@ -416,6 +431,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     fw0 = *(const par_u32u *)(gsrc);
                     fw1 = *(const par_u32u *)(gsrc + flast);
                 }
+#endif
             }
             // prefetch the next window while this batch is copied
             {
@@ -427,6 +443,53 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // ---------------- dependency masks (independent of the copies below: issued first so that
             // their cross-lane traffic overlaps the literal and far copies) ----------------
             uint64_t need = 0;
+#if PAR_RANK
+            {
+                // Which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?  Sequence starts are
+                // bits of a bit vector over the batch's output positions (relative to op; <= PAR_BATCH_OUT of them); the
+                // sequence that holds position x is (number of set bits at or below x) - 1.  The vector lives where the jump
+                // table was (the chain is done with it): one 16-byte record per 64 positions = {bits 0-31, bits 32-63, set
+                // bits in the records before}, so a query is ONE aligned 16-byte gather and two popcounts -- instead of a
+                // six-step binary search over the lanes (12 ds_bpermute and their address arithmetic per batch).
+                static_assert(16 * (PAR_BATCH_OUT / 64 + 1) <= 2 * PAR_NODES, "rank records fit the jump table");
+                uint8_t *rk = (uint8_t *)L.jump;
+                constexpr int NREC = PAR_BATCH_OUT / 64 + 1;
+                {
+                    uint32_t z = 0;
+                    asm volatile("" : "+v"(z));     // made here: a zero vector kept across the loop costs four registers (it was spilled)
+                    if (lane < NREC) *(uint4 *)&rk[16 * lane] = make_uint4(z, z, z, z);
+                }
+                wave_fence();
+                if (act) {
+                    const uint32_t rel = (uint32_t)(outStart - op);
+                    atomicOr((uint32_t *)&rk[16u * (rel >> 6) + 4u * ((rel >> 5) & 1u)], 1u << (rel & 31u));
+                }
+                wave_fence();
+                {
+                    uint2 w = make_uint2(0u, 0u);
+                    if (lane < NREC) w = *(const uint2 *)&rk[16 * lane];
+                    const int cnt = (int)__builtin_popcount(w.x) + (int)__builtin_popcount(w.y);
+                    const int pre = par_scan_incl(cnt) - cnt;
+                    if (lane < NREC) *(uint32_t *)&rk[16 * lane + 8] = (uint32_t)pre;
+                }
+                wave_fence();
+                const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
+                if (act && nearSrc && srcHi > op && srcHi > spos) {
+                    const uint32_t xlo = (uint32_t)(max(spos, op) - op), xhi = (uint32_t)(srcHi - 1 - op);
+                    auto rank = [&](uint32_t x) -> int {
+                        const uint4 r = *(const uint4 *)&rk[16u * (x >> 6)];
+                        const uint32_t m = (2u << (x & 31u)) - 1u;          // bits 0 .. x & 31
+                        const bool hi = (x & 32u) != 0u;
+                        return (int)r.z + (int)__builtin_popcount(r.x & (hi ? ~0u : m)) + (int)__builtin_popcount(r.y & (hi ? m : 0u)) - 1;
+                    };
+                    const int jlo = rank(xlo), jhi = rank(xhi);
+                    const uint64_t upto = (jhi >= 63) ? ~0ull : ((1ull << (jhi + 1)) - 1ull);
+                    need = upto & ~((1ull << jlo) - 1ull);
+                    need &= ~(1ull << lane);
+                }
+                wave_fence();
+            }
+#else
             {
                 // which sequences of this batch does my source [spos, min(spos+ml, outStart)) overlap?
                 const int srcHi = min(spos + (int)ml, outStart);        // bytes >= outStart are my own literals
@@ -445,6 +508,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     need &= ~(1ull << lane);
                 }
             }
+#endif
             // ---------------- 5. literals: window -> ring ----------------
             {
                 const uint32_t sA = litStart;
@@ -484,6 +548,18 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             // ---------------- 6. far matches, second half: into the ring (behind the literals: a literal store
             // may run over into its own sequence's match area) ----------------
             if (farm) {
+#if PAR_FAR_WIDE
+                if (fstep == 16 && ml <= 16u) f1 = f0;
+                {
+                    const uint32_t sh = ml - 8u;                                     // 8-byte class: 0..7
+                    const bool up = (sh & 4u) != 0u;
+                    const uint32_t lo = up ? f0.y : f0.x, mid = up ? f0.z : f0.y, hi = up ? f0.w : f0.z;
+                    fa = (uint64_t)f0.x | ((uint64_t)f0.y << 32);
+                    fb = (uint64_t)__builtin_amdgcn_alignbyte(mid, lo, sh & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(hi, mid, sh & 3u) << 32);
+                    fw0 = f0.x;
+                    fw1 = __builtin_amdgcn_alignbyte(f0.y, f0.x, (ml - 4u) & 3u);   // 4-byte class: ml - 4 = 0..3
+                }
+#endif
                 if (farMine && fstep == 16) {
                     *(par_v4u *)&L.ring[mdA] = f0;
                     *(par_v4u *)&L.ring[mdA + min(16u, flast)] = f1;
@@ -624,19 +700,19 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 const int newBase = (op - PAR_HIST) & ~15;
                 const int delta = newBase - ringBase;
                 const int n16 = (op - newBase + (int)A + 15) >> 4;
-                // history + the alignment head: at most PAR_HIST + 31 bytes, i.e. three chunks per lane at the most;
+                // history + the alignment head: at most PAR_HIST + 15 + 15 + 15 bytes in chunks of 16, PAR_SLIDE chunks per lane;
                 // all of them are read before the first is written (one LDS round trip, and the ranges may overlap)
-                static_assert(PAR_HIST + 32 <= 3 * 16 * LZ4_WAVE, "the slide moves at most three chunks per lane");
+                constexpr int PAR_SLIDE = (PAR_HIST + 45 + 16 * LZ4_WAVE - 1) / (16 * LZ4_WAVE);
                 {
-                    uint4 v[3];
+                    uint4 v[PAR_SLIDE];
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {
+                    for (int i = 0; i < PAR_SLIDE; i++) {
                         const int k = lane + i * LZ4_WAVE;
                         v[i] = (k < n16) ? *(const uint4 *)&L.ring[delta + 16 * k] : make_uint4(0u, 0u, 0u, 0u);
                     }
                     wave_fence();
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {
+                    for (int i = 0; i < PAR_SLIDE; i++) {
                         const int k = lane + i * LZ4_WAVE;
                         if (k < n16) *(uint4 *)&L.ring[16 * k] = v[i];
                     }
