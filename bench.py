@@ -62,8 +62,9 @@ def canterbury_large(n_bytes):
     return b"".join(parts), "Canterbury large (bible.txt, E.coli, world192.txt cycled)"
 
 
-def reference_stream_decode(S, eng, torch, dev, comps, src, ns, BL):
-    """GPU decode (linked = 1) of a stream of `ns` blocks written by the reference's linked compressor."""
+def reference_stream_decode(S, eng, torch, dev, comps, src, ns, BL, linked=True):
+    """GPU decode of a stream of `ns` blocks written by the reference's compressor: its own linked stream (linked = 1,
+    the only thing compressChunks ever writes) or the same blocks compressed independently (linked = 0)."""
     import struct
     import numpy as np
     framed = b"".join(struct.pack("<ii", len(c), BL) + c for c in comps)
@@ -81,15 +82,62 @@ def reference_stream_decode(S, eng, torch, dev, comps, src, ns, BL):
     best = 1e9
     for _ in range(3):
         eng.record(e0)
-        eng.decompress_batch_device(buf, len(framed), off, ns, out, ooff, res, linked=True)
+        eng.decompress_batch_device(buf, len(framed), off, ns, out, ooff, res, linked=linked)
         eng.record(e1)
         eng.synchronize()
         best = min(best, eng.elapsed_ms(e0, e1))
     ok = bool((res == BL).all().item()) and torch.equal(out, src[: ns * BL])
     if not ok:
-        sys.exit("bench.py: the reference-written linked stream does not decode to the input")
-    return {"blocks": ns, "dependent_blocks": dependent, "ms": round(best, 3), "GBps": round(ns * BL / best / 1e6, 2),
-            "verified": True, "note": "one linked stream, one call; device-resident, HIP events"}
+        sys.exit("bench.py: the reference-written %s stream does not decode to the input" % ("linked" if linked else "independent"))
+    r = {"blocks": ns, "dependent_blocks": dependent, "ms": round(best, 3), "GBps": round(ns * BL / best / 1e6, 2),
+         "verified": True}
+    if linked:
+        r["note"] = "one linked stream, one call; device-resident, HIP events"
+    else:
+        r["ratio"] = round(ns * BL / len(framed), 4)
+        r["frac"] = round((ns * BL + len(framed)) / best / 1e6 / HBM_PEAK_GBPS, 5)
+        r["note"] = ("the same blocks compressed INDEPENDENTLY by the reference codec on the host (fresh context per block), "
+                     "decoded by the kernel `value` times; device-resident, HIP events, best of 3")
+    return r
+
+
+def incompressible_rates(S, eng, torch, dev):
+    """The north star's "compressible and incompressible": 4 GiB of random bytes in 256 KiB blocks at acceleration 400
+    (BASELINE configs[4]'s per-GPU share), compress and decompress timed with HIP events, round trip checked."""
+    BL, NB, accel = 262144, 16384, 400
+    U = NB * BL
+    src = torch.empty(U, dtype=torch.uint8, device=dev)
+    eng.generate("random", src, BL, NB)
+    stride = S.slot_stride(BL, 8)
+    slots = torch.empty(NB * stride, dtype=torch.uint8, device=dev)
+    flen = torch.empty(NB, dtype=torch.int32, device=dev)
+    doff = torch.empty(NB + 1, dtype=torch.int64, device=dev)
+    dense = torch.empty(NB * stride, dtype=torch.uint8, device=dev)
+    ooff = torch.arange(NB + 1, dtype=torch.int64, device=dev) * BL
+    out = torch.empty(U, dtype=torch.uint8, device=dev)
+    res = torch.empty(NB, dtype=torch.int32, device=dev)
+    ev = [S.Event() for _ in range(3)]
+    tc = td = 1e9
+    C = 0
+    for _ in range(3):
+        eng.record(ev[0])
+        eng.compress_batch_device(src, NB, BL, slots, stride, flen, accel=accel)
+        eng.record(ev[1])
+        eng.compact_device(slots, stride, flen, NB, dense, NB * stride, doff)
+        eng.synchronize()
+        C = int(doff[-1].item())
+        tc = min(tc, eng.elapsed_ms(ev[0], ev[1]))
+        eng.record(ev[1])
+        eng.decompress_batch_device(dense, C, doff, NB, out, ooff, res)
+        eng.record(ev[2])
+        eng.synchronize()
+        td = min(td, eng.elapsed_ms(ev[1], ev[2]))
+    if not (bool((res == BL).all().item()) and torch.equal(out, src)):
+        sys.exit("bench.py: incompressible round trip mismatch")
+    return {"workload": "random bytes, 256 KiB blocks, %d blocks (4 GiB), accel %d" % (NB, accel), "ratio": round(U / C, 5),
+            "decompress_GBps": round(U / td / 1e6, 2), "decompress_frac": round((U + C) / td / 1e6 / HBM_PEAK_GBPS, 5),
+            "compress_GBps": round(U / tc / 1e6, 2), "compress_frac": round((U + C) / tc / 1e6 / HBM_PEAK_GBPS, 5),
+            "verified": True, "note": "HIP events, best of 3, device-resident"}
 
 
 def host_api_rates(S, eng, src, BL, kind):
@@ -213,6 +261,34 @@ def one_stream_bench(args, torch, S, dist, eng, dev, rank, world, red_dev, kind,
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Run this script's command line under `python -m torch.distributed.run --nproc-per-node n` as a child process, relay
+    rank 0's single JSON line (the ranks' other output goes to stderr) and return the child's exit code."""
+    import socket
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith("{") and line is None:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +313,12 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-buffer API figures (N=1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a CHILD process (torch.distributed.run, one rank per
+        # GPU) and hand back its exit code.  This process has not imported torch or touched the GPU, and it never
+        # replaces itself: the ranks are children of the child.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import streamly_lz4_amd as S
 
@@ -244,8 +326,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d runs under WORLD_SIZE=%d: launch it with torch.distributed.run --nproc-per-node %d, "
+                 "or without WORLD_SIZE set to let it start the ranks itself" % (args.gpus, world, args.gpus))
     dist = None
     # BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only to rehearse the N>1 code path on a 1-GPU box
     # (all ranks on one device, gloo rendezvous); the driver's launch uses one GPU per rank over RCCL.
@@ -485,6 +567,12 @@ def main():
         # the block before it) decoded by the GPU in one call, linked = 1, and compared with the input.
         cpu["reference_stream_gpu_decode"] = reference_stream_decode(S, eng, torch, dev, r["stream"], src, ns, BL)
         del r["stream"]
+        # ... and the same sample compressed block by block with a fresh reference context (independent blocks): what the
+        # timed kernel does on a stream it did not write itself
+        codec = orc.Reference() if r["kind"] == "reference" else orc.Oracle()
+        indep = [codec.compress_block(b, accel) for b in blocks]
+        cpu["decode_reference_written_independent"] = reference_stream_decode(S, eng, torch, dev, indep, src, ns, BL, linked=False)
+        del indep
         if not args.no_cpu_all_cores:
             # best-case CPU, NOT reference behaviour (its API is one serial stream): one independent
             # linked context per host thread over contiguous block ranges of the same sample
@@ -500,16 +588,21 @@ def main():
         "dtype": "u8", "data": data_name,
         "config": {"workload": "%s: %s, %d KiB blocks, %d blocks (%.2f GiB) per GPU, %s, accel %d, %s, "
                                "round-robin block->GPU%s" % (args.workload, phase, BL >> 10, NB, U / 2 ** 30, kind, accel,
-                                                             "ONE LINKED stream per GPU (previous block = dictionary)"
-                                                             if args.linked_compress else "independent blocks",
+                                                             "ONE LINKED stream per GPU (previous block = dictionary), written by this engine"
+                                                             if args.linked_compress else
+                                                             "independent blocks WRITTEN BY THIS ENGINE's compressor during setup",
                                                              ", linked=1" if args.linked else ""),
                    "block_len": BL, "blocks_per_gpu": NB, "ratio": round(U / Cbytes, 4), "decoder": args.decoder},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "kernels_ms": {k: round(v, 4) for k, v in timed_ms.items() if v},
     }
+    if cpu is not None and "decode_reference_written_independent" in cpu:
+        line["decode_reference_written_independent_GBps"] = cpu["decode_reference_written_independent"]["GBps"]
     if extra is not None:
         line["roundtrip"] = extra
+    if world == 1 and not args.no_extra and args.workload != "random256k" and corpus_bytes is None:
+        line["incompressible"] = incompressible_rates(S, eng, torch, dev)
     if world == 1 and not args.no_host_api and kind != "canterbury-large":
         line["host_api_pcie_inclusive"] = host_api_rates(S, eng, src, BL, kind)
     if gather is not None:

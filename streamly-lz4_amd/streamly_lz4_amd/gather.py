@@ -5,8 +5,8 @@ rank k % G as that rank's local block k // G.  Compute needs no collective.  To
 hand one in-order stream to a single consumer:
 
   1. all_gather of the per-block byte counts (int32)  -> every rank knows every size;
-  2. each peer sends its dense local buffer to the root over its direct xGMI link
-     (torch.distributed isend/irecv == ncclSend/ncclRecv on the RCCL backend; no ring);
+  2. each peer sends its dense local buffer to the root over its direct xGMI link, every peer's transfer of a round
+     in ONE batch (dist.batch_isend_irecv == ncclGroupStart / ncclSend, ncclRecv / ncclGroupEnd on RCCL; no ring);
   3. the root scatters block (g, j) to globalOff[j*G + g] -- the HIP interleave
      kernel (mi355lz4_interleave_device) on the GPU.
 
@@ -87,10 +87,19 @@ def gather_ordered(local, local_sizes, root=0, engine=None, group=None, stage_by
     limit = int(stage_bytes or STAGE_BYTES)
     sizes, goff = global_layout(local_sizes, group)
     sizes64 = [x.to(torch.int64).cpu() for x in sizes]
+    # The transfers of one piece ROUND -- piece k of every peer that has one -- are posted as ONE batch
+    # (dist.batch_isend_irecv == ncclGroupStart ... ncclGroupEnd on the RCCL backend): every peer's
+    # send/receive pair of the round is in flight at once, each on the peer's own xGMI link.  Posted one by one, point
+    # to point operations on one communicator run in posting order and the root would drain peer 1 before peer 2.
+    # (The piece number is also the message tag: gloo does not match equal tags in order; RCCL ignores tags and is FIFO.)
+    def batch(ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
     if rank != root:
-        # (the piece number is the message tag: gloo does not match equal tags in order; RCCL ignores tags and is FIFO)
-        reqs = [dist.isend(local[b0:b1].contiguous(), dst=root, group=group, tag=k)
-                for k, (_j0, _j1, b0, b1) in enumerate(pc for pc in _pieces(sizes64[rank], limit) if pc[3] > pc[2])]
+        pcs = [pc for pc in _pieces(sizes64[rank], limit) if pc[3] > pc[2]]
+        reqs = []
+        for k, (_j0, _j1, b0, b1) in enumerate(pcs):           # a peer queues all its rounds without waiting
+            reqs += batch([dist.P2POp(dist.isend, local[b0:b1].contiguous(), root, group=group, tag=k)])
         for r in reqs:
             r.wait()
         return None, goff
@@ -106,37 +115,35 @@ def gather_ordered(local, local_sizes, root=0, engine=None, group=None, stage_by
         torch.cumsum(sizes[g].to(torch.int64), 0, out=poff[1:])
         pcs = [pc for pc in _pieces(sizes64[g], limit) if pc[3] > pc[2]]
         cap = max([pc[3] - pc[2] for pc in pcs], default=0)
-        peers.append({"g": g, "poff": poff, "pieces": pcs, "next": 0, "inflight": [],
+        peers.append({"g": g, "poff": poff, "pieces": pcs,
                       "stages": [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(min(2, len(pcs)))]})
+    rounds = max([len(p["pieces"]) for p in peers], default=0)
 
-    def post(p):
-        while p["next"] < len(p["pieces"]) and len(p["inflight"]) < len(p["stages"]):
-            k = p["next"]
-            j0, j1, b0, b1 = p["pieces"][k]
-            stage = p["stages"][k % len(p["stages"])][: b1 - b0]
-            p["inflight"].append((k, stage, dist.irecv(stage, src=p["g"], group=group, tag=k)))
-            p["next"] += 1
+    def post_round(k):
+        ops, meta = [], []
+        for p in peers:
+            if k < len(p["pieces"]):
+                _j0, _j1, b0, b1 = p["pieces"][k]
+                stage = p["stages"][k % len(p["stages"])][: b1 - b0]
+                ops.append(dist.P2POp(dist.irecv, stage, p["g"], group=group, tag=k))
+                meta.append((p, stage))
+        return k, meta, batch(ops)
 
-    for p in peers:
-        post(p)
-    interleave(local, loff, root, G, out, goff, engine)                  # overlaps with the receives
-    busy = True
-    while busy:
-        busy = False
-        for p in peers:                                                   # round-robin over the peers: one piece each
-            if not p["inflight"]:
-                continue
-            busy = True
-            k, stage, req = p["inflight"].pop(0)
-            req.wait()
+    inflight = [post_round(k) for k in range(min(2, rounds))]    # two staging buffers per peer: two rounds in flight
+    interleave(local, loff, root, G, out, goff, engine)          # overlaps with the receives
+    while inflight:
+        k, meta, reqs = inflight.pop(0)
+        for r in reqs:
+            r.wait()
+        for p, stage in meta:
             _order_engine_after_torch(engine, stage)
             j0, j1, b0, b1 = p["pieces"][k]
             interleave(stage, p["poff"][j0:j1 + 1] - b0, p["g"], G, out, goff[j0 * G:], engine)
-            if stage.is_cuda and len(p["pieces"]) > len(p["stages"]):
-                # the staging buffer is reused by a later receive: the kernel that reads it must be done first
-                if engine is not None:
-                    engine.synchronize()
-            post(p)
+        if k + 2 < rounds:
+            # round k + 2 receives into the staging buffers round k used: the kernels that read them must be done first
+            if out.is_cuda and engine is not None:
+                engine.synchronize()
+            inflight.append(post_round(k + 2))
     if out.is_cuda:
         if engine is not None:
             engine.synchronize()

@@ -53,3 +53,18 @@ def test_gather_ordered_world2(n_global, stage_bytes):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("n_global,stage_bytes", [(9, None), (63, 300), (66, 1)])
+def test_gather_ordered_world3(n_global, stage_bytes):
+    """Two peers per piece round (one batch of receives on the root), with unequal piece counts per peer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + n_global + (stage_bytes or 0) % 97
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, n_global, 11, q, stage_bytes)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

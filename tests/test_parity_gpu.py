@@ -483,6 +483,26 @@ def test_roundtrip_config2_full_size(slz4, engine, oracle):
         assert code == bl and out == oracle.gen("lzsynth", 1, bl, first_block=i).tobytes()
 
 
+@pytest.mark.parametrize("kind", ["lzsynth", "text"])
+def test_decode_config2_reference_written_256MiB(engine, oracle, kind):
+    """BASELINE config 2 says "bit-exact vs ref": 256 MiB (4096 blocks of 64 KiB) of INDEPENDENT blocks written by the
+    CPU oracle's compressor (byte-identical to the reference's, tests/test_oracle.py) go through both decoder kernels --
+    the sequence-at-a-time one and the lane-parallel one -- and must give the generator's bytes back."""
+    nb, bl = 4096, 65536
+    data = oracle.gen(kind, nb, bl, first_block=1 << 20).tobytes()
+    fr = oracle.frame_compress(data, bl, 1, 8, False)
+    want = sha(data)
+    try:
+        for decoder in (1, 2):
+            engine.set_decoder(decoder)
+            out, blen = engine.decompress_batch(fr)
+            assert blen == [bl] * nb, (kind, decoder)
+            assert sha(out) == want and out == data, (kind, decoder)
+            del out
+    finally:
+        engine.set_decoder(0)
+
+
 def test_roundtrip_config5_random_256k(slz4, engine):
     """BASELINE config 5: accel 400, incompressible input, 256 KiB blocks (4 GiB)."""
     nb, bl = 16384, 262144
