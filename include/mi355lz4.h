@@ -100,12 +100,22 @@ int mi355lz4_synchronize(mi355lz4_ctx *ctx);
  * the first pass found nothing to do (about a dozen empty launches per 4096 blocks).  The call can then be captured in
  * a graph and no longer serialises a caller's pipeline; it costs more than the wait on big batches of independent
  * blocks (measured in DESIGN.md), which is why it is opt-in.  0 restores the default.  The streams call
- * (mi355lz4_decompress_streams_device) always waits. */
+ * (mi355lz4_decompress_streams_device) always waits.
+ * Before capturing such a call in a graph, make ONE warm-up call with the largest batch the graph will see: the
+ * scratch is sized for ALL blocks of the call whether or not any is dependent (lists: one byte per output byte, up
+ * to 16384 blocks' worth; source pointers: four bytes per output byte of a 4096-block segment, about 1 GiB) and is
+ * allocated (hipMalloc / hipFree, not capturable) the first time a call needs more than the engine holds. */
 int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
 /* Small batches.  With fewer blocks in a call than the chip has wave slots, the compressor cuts every block
  * (8 KiB .. 4 MiB, independent blocks) into segments that several wavefronts compress at once (a block still
  * comes out as one valid LZ4 block; the seams cost about 1 % of size on text).  segs: -1 = automatic (default;
- * MI355LZ4_SEG in the environment overrides it), 0 = never, 2..64 = that many segments whenever possible. */
+ * MI355LZ4_SEG in the environment overrides it), 0 = never, 2..64 = that many segments whenever possible.
+ * Consequences a caller should know: (1) the compressed BYTES of a block depend on how many blocks share the call
+ * (the small tail batch of a stream is cut into segments, the big batches before it are not); every form decodes to
+ * the same data, and segs = 0 gives bytes that do not depend on the batch.  (2) The segment path keeps a device
+ * scratch of about twice the call's input per stream it was used on (at most four streams; a fifth takes over the
+ * slot used longest ago) until mi355lz4_destroy; automatic mode leaves the path alone once that scratch would pass
+ * 1 GiB, a forced count does not. */
 int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
 /* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel,
  * 2 = lane-parallel kernel.  Tuning/ablation knob; results are identical. */
@@ -259,9 +269,12 @@ int mi355lz4_decompress_linked_begin(mi355lz4_ctx *ctx, const uint8_t *framed, u
 int mi355lz4_decompress_linked_end(mi355lz4_ctx *ctx);
 /* Between _begin and _end: make the LAST block of the range final ahead of the others, so that it can go to the rank
  * that holds the next range while this rank's own fetch is still to run (a stream over G GPUs then waits G times for
- * one block, not for a range).  Returns 1 when result[nBlocks-1] / the block's bytes are final after this call
- * (the call waits for them), 0 when they are not available this way -- call _end first -- or a negative
- * MI355LZ4_E_* code.  _end must still be called.  (Reference semantics as for _begin: cbits/lz4.c:2347-2355.) */
+ * one block, not for a range).  The seam -- the output of the block in front of the range (lookBack) -- must be in
+ * place before this call, exactly as for _end: the fetch reads it.  Returns 1 when the last block's BYTES are final
+ * after this call (the call waits for them), 0 when they are not available this way -- call _end first -- or a
+ * negative MI355LZ4_E_* code.  Only the bytes are final: result[nBlocks-1] keeps the first pass's code until _end has
+ * run, so take the block's size from its header (or from the capacity handed in), not from result[].  _end must still
+ * be called.  (Reference semantics as for _begin: cbits/lz4.c:2347-2355.) */
 int mi355lz4_decompress_linked_end_last(mi355lz4_ctx *ctx);
 
 /* ---- synthetic inputs (bench / test support; SURVEY.md 8d generators) ---

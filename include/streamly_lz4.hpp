@@ -104,6 +104,8 @@ struct ArrayBatch {
 };
 ArrayBatch decompressChunksBatch(const BlockConfig &cfg, const FrameConfig &conf, const uint8_t *data,
                                  const uint64_t *lens, size_t n, Engine &eng);
+// Released result buffers are kept for the next call (at most four, 64 MiB in all); this hands them back to the allocator.
+void trimBuffers();
 // simpleFrameParserD                (Internal/LZ4.hs:590-651): consumes the 7-byte
 // frame header from the head of the stream; returns the parsed configs and the
 // stream of what follows.

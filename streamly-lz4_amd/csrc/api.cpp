@@ -165,8 +165,9 @@ struct mi355lz4_ctx {
     } plan;
     // small-batch compression: per-segment sequence lists, one scratch buffer per stream the engine has been used on
     // (the host pipelines run two groups at a time on two compute streams; work on ONE stream is ordered)
-    struct SegScratch { hipStream_t s = nullptr; DevBuf b; } seg[4];
+    struct SegScratch { hipStream_t s = nullptr; DevBuf b; unsigned long long tick = 0; } seg[4];
     int nSeg = 0;
+    unsigned long long segTick = 0;
     int linkedAsyncCap = 0;                // > 0: linked device decodes do not wait on the host (mi355lz4_set_linked_async)
     int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
@@ -493,9 +494,31 @@ static int encode_device(mi355lz4_ctx *c, const uint8_t *src, const uint64_t *sr
             sa.listStride = (size_t)maxBlockLen / 4 + (size_t)segs + 2;
             const size_t listBytes = (size_t)nBlocks * sa.listStride * sizeof(uint64_t);
             const size_t cntBytes = (size_t)nBlocks * (size_t)segs * sizeof(uint32_t);
-            DevBuf *sb = nullptr;
-            for (int i = 0; i < c->nSeg; i++) if (c->seg[i].s == c->stream) sb = &c->seg[i].b;
-            if (!sb && c->nSeg < 4) { c->seg[c->nSeg].s = c->stream; sb = &c->seg[c->nSeg++].b; }
+            // The record lists are twice the input.  Automatic mode only takes the segment path while they stay under
+            // SEG_SCRATCH_MAX (a call of 2048 x 4 MiB would otherwise pin 20 GiB per stream until mi355lz4_destroy:
+            // round-3 advisor finding); a forced count (tests, mi355lz4_set_segments(k)) is the caller's decision.
+            const size_t SEG_SCRATCH_MAX = (size_t)1 << 30;
+            const bool fits = segEnv > 0 || listBytes + 3 * cntBytes <= SEG_SCRATCH_MAX;
+            // One scratch per stream the engine has been used on, four at the most: a fifth stream takes over the slot
+            // that was used longest ago, once the work queued on that slot's stream is done with it.
+            mi355lz4_ctx::SegScratch *slot = nullptr;
+            if (fits) {
+                for (int i = 0; i < c->nSeg; i++) if (c->seg[i].s == c->stream) slot = &c->seg[i];
+                if (!slot && c->nSeg < 4) { slot = &c->seg[c->nSeg++]; slot->s = c->stream; }
+                if (!slot) {
+                    slot = &c->seg[0];
+                    for (int i = 1; i < c->nSeg; i++) if (c->seg[i].tick < slot->tick) slot = &c->seg[i];
+                    (void)hipStreamSynchronize(slot->s);
+                    slot->s = c->stream;
+                }
+                slot->tick = ++c->segTick;
+                // a scratch that a big forced call left behind is given back when a call needs less than a quarter of it
+                if (slot->b.cap > SEG_SCRATCH_MAX && (listBytes + 3 * cntBytes + 256) * 4 < slot->b.cap) {
+                    (void)hipStreamSynchronize(slot->s);
+                    dev_release(slot->b);
+                }
+            }
+            DevBuf *sb = slot ? &slot->b : nullptr;
             if (sb && dev_reserve(*sb, listBytes + 3 * cntBytes + 256) == 0) {
                 sa.lists = (uint64_t *)sb->p;
                 sa.segCount = (uint32_t *)((uint8_t *)sb->p + ((listBytes + 63) & ~(size_t)63));
@@ -633,7 +656,10 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     }
     if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
     const int first = (int)stat[1], last = (int)stat[2];
-    if (first < 0 || last >= nBlocks || first > last) return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
+    if (first < 0 || last >= nBlocks || first > last) {
+        link_scratch_release(c);          // the first pass is in flight on linkBuf: the next linked call must be ordered behind it
+        return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
+    }
     // Lists of deferred matches for up to POOL_BLOCKS dependent blocks at a time (64 KiB each: one byte per output
     // byte) and source pointers for up to PTR_BLOCKS of them (four bytes per output byte); without the lists the
     // blocks are walked one after the other.  (Read per call: the tests shrink both to reach every seam.)

@@ -356,6 +356,7 @@ struct BufPool {
             for (size_t i = 0; i < free_.size(); i++)
                 if (free_[i].first >= n && free_[i].first <= 2 * n + (1u << 20)) {
                     uint8_t *p = free_[i].second; cap = free_[i].first;
+                    held -= cap;
                     free_.erase(free_.begin() + (long)i);
                     return p;
                 }
@@ -363,16 +364,28 @@ struct BufPool {
         cap = n;
         return new uint8_t[n];
     }
+    // The pool holds at most four buffers and POOL_BYTES in all (round 3 kept up to 4 x 256 MiB for the life of the
+    // process); slz4_trim() / trim() hands everything back.
+    static constexpr size_t POOL_BYTES = (size_t)64 << 20;
+    size_t held = 0;
     void put(uint8_t *p, size_t cap)
     {
         std::lock_guard<std::mutex> g(mu);
-        if (free_.size() < 4 && cap <= ((size_t)256 << 20)) { free_.emplace_back(cap, p); return; }
+        if (free_.size() < 4 && held + cap <= POOL_BYTES) { free_.emplace_back(cap, p); held += cap; return; }
         delete[] p;
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &f : free_) delete[] f.second;
+        free_.clear();
+        held = 0;
     }
 };
 BufPool &buf_pool() { static BufPool *p = new BufPool(); return *p; }
 } // namespace
 void ArrayBatch::release() { if (buf) { buf_pool().put(buf, cap); buf = nullptr; cap = 0; } }
+void trimBuffers() { buf_pool().trim(); }
 
 // decompressChunks over arrays that already lie back to back (streamly_lz4.hpp): when the bytes are a well-formed
 // run of whole blocks that all decode, one index walk and one GPU call do what resizeChunksD + decompressChunksRawD do
@@ -586,6 +599,8 @@ size_t slz4_arrays_count(const slz4_arrays *a) { return a ? (a->flat ? a->b.coun
 size_t slz4_arrays_len(const slz4_arrays *a, size_t i) { return a->flat ? a->b.off[i + 1] - a->b.off[i] : a->v[i].size(); }
 const uint8_t *slz4_arrays_data(const slz4_arrays *a, size_t i) { return a->flat ? a->b.buf + a->b.off[i] : a->v[i].data(); }
 void slz4_arrays_free(slz4_arrays *a) { delete a; }
+// result buffers kept for reuse (<= 64 MiB in all) go back to the allocator
+void slz4_trim(void) { streamly_lz4::trimBuffers(); }
 // flat results (the batch forms): the shared buffer and the n + 1 offsets; returns 0 when `a` is not flat
 int slz4_arrays_flat(const slz4_arrays *a, const uint8_t **base, const size_t **offsets)
 {

@@ -239,11 +239,14 @@ Array lz4FrameDecompress(const Array &frame, Engine &eng)
         // the last 64 KiB of the frame -- the same thing as long as blocks are full.  So a group also ends behind a
         // block that came out short (a writer that flushed in mid-frame; never liblz4's one-shot LZ4F_compressFrame
         // or the CLI): the block after it starts the next group and gets the frame's window as that call's dictionary.
-        size_t g0 = 0;
+        // After a cut behind a short block the next group starts small and doubles while groups come out whole: a frame
+        // of N flushed short blocks then costs O(N) block decodes, not N groups of thousands of blocks each (round-3
+        // advisor finding).
+        size_t g0 = 0, groupLimit = (size_t)-1;
         while (g0 < nBlocks) {
             // capacity per block of this group and how many blocks fit the budget
             size_t cap = 0, g1 = g0;
-            while (g1 < nBlocks) {
+            while (g1 < nBlocks && g1 - g0 < groupLimit) {
                 const size_t clen = blockAt[g1 + 1] - blockAt[g1] - 4;
                 const size_t c1 = std::max(cap, std::min(bmax, clen * 255 + 16));
                 if (g1 > g0 && (g1 - g0 + 1) * c1 > LZ4F_GROUP_BUDGET) break;
@@ -278,9 +281,18 @@ Array lz4FrameDecompress(const Array &frame, Engine &eng)
                 // the group's first block had the whole window and still fails: the frame is damaged
                                 throw Error(std::string("lz4FrameDecompress: ") + (r == MI355LZ4_OK ? "block decode failed" : mi355lz4_last_error()));
             }
-            if (keep < nb || r != MI355LZ4_OK) {
+            if (keep < nb && r == MI355LZ4_OK) {
+                // every block decoded; the ones that stand had their whole window and lie packed at the front of the
+                // scratch: keep those bytes, drop the rest (no second decode)
+                got = 0;
+                for (size_t k = 0; k < keep; k++) got += (size_t)blen[k];
+                nb = keep;
+                g1 = g0 + keep;
+                groupLimit = 2;
+            } else if (keep < nb || r != MI355LZ4_OK) {
                 // decode exactly the blocks that stand (what a failed call leaves in the output buffer is not part of the
                 // C ABI's contract)
+                groupLimit = 2;
                 nb = keep;
                 g1 = g0 + keep;
                 r = mi355lz4_decompress_batch(eng.ctx(), framed.data() + blockAt[g0], blockAt[g1] - blockAt[g0], 4, (int)cap,
@@ -288,6 +300,7 @@ Array lz4FrameDecompress(const Array &frame, Engine &eng)
                                               (int)nb, &nbOut);
                 if (r != MI355LZ4_OK) throw Error(std::string("lz4FrameDecompress: ") + mi355lz4_last_error());
             }
+            else if (groupLimit != (size_t)-1) groupLimit = (groupLimit > ((size_t)-1) / 2) ? (size_t)-1 : groupLimit * 2;
             out.insert(out.end(), scratch.data(), scratch.data() + got);
             g0 = g1;
         }

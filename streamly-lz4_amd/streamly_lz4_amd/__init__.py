@@ -130,6 +130,7 @@ def _load():
     sig("slz4_arrays_len", C.c_size_t, vp, C.c_size_t)
     sig("slz4_arrays_data", _u8p, vp, C.c_size_t)
     sig("slz4_arrays_free", None, vp)
+    sig("slz4_trim", None)
     sig("slz4_compress_chunks", C.c_int, vp, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
     sig("slz4_resize_chunks", C.c_int, C.c_int, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
     sig("slz4_decompress_chunks_raw", C.c_int, vp, C.c_int, _u8p, _u64p, C.c_size_t, C.POINTER(vp))
