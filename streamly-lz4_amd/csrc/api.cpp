@@ -615,7 +615,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.out = out; a.outOff = outOff; a.outCap = outCap; a.result = result;
     a.dict0 = dict0; a.dict0Len = dict0Len;
     a.streamFirst = streamFirst; a.nStreams = nStreams; a.lookBack = lookBack;
-    a.tolPool = nullptr; a.tolRegions = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
+    a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = nBlocks; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr;
     a.asyncGate = 0;
@@ -684,7 +684,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     int seg = pool;
     if (poolMax > 0 && !walkStreams && dev_reserve(c->tolPool, (size_t)pool * per * tol_region_bytes()) == 0 &&
         dev_reserve(c->tolMeta, ((size_t)nBlocks * 3 + 4) * sizeof(int32_t)) == 0) {
-        a.tolPool = c->tolPool.p; a.tolRegions = pool * per;
+        a.tolPool = c->tolPool.p; a.tolRegions = pool * per; a.tolPer = per;
         a.tolCounter = (uint32_t *)c->tolMeta.p;
         a.tolRegion = (int32_t *)c->tolMeta.p + 4;
         a.tolCount = a.tolRegion + nBlocks;

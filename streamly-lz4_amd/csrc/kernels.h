@@ -34,6 +34,7 @@ struct DecodeArgs {
     // and the pool its deferred lists live in; all null when the pool is not available
     void *tolPool;                // TolEntry[tolRegions][TOL_LIST_CAP]
     int tolRegions;
+    int tolPer;                   // list regions per block of a tolerant launch: block segFirst + i owns regions [i * tolPer, (i + 1) * tolPer)
     uint32_t *tolCounter;         // regions handed out so far
     int32_t *tolRegion;           // per block: region index, or -1 (no list: serial path)
     int32_t *tolCount;            // per block: entries appended (may exceed the capacity: overflow)

@@ -51,14 +51,51 @@ __device__ __forceinline__ int read_block_header(const DecodeArgs &a, int blk, c
 // A codec error (not a header rejection) is what a block of a linked stream reports when it is decoded without
 // its dictionary: the second pass is launched only when the standalone pass counted some.
 __device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7F000000; }
-__device__ __forceinline__ void note_link_failure(const DecodeArgs &a, int blk, int r, int cap)
+
+// linkStat = {dependent blocks, first, last, -, largest capacity among them}, from result[] once the standalone pass
+// is done.  (Round 3 had every failing block add to these five words itself: four atomics per block on ONE cache line,
+// 16 384 of them for a reference-written stream of 4096 blocks, which cost the standalone pass 0.33 of its 0.38 ms --
+// the blocks themselves give up at their first sequence.)  One workgroup per 1024 blocks, one set of atomics each.
+__global__ __launch_bounds__(1024) void k_link_stat(DecodeArgs a)
 {
-    if (a.linkStat && is_codec_error(r)) {
-        atomicAdd(&a.linkStat[0], 1u);
-        atomicMin(&a.linkStat[1], (uint32_t)blk);
-        atomicMax(&a.linkStat[2], (uint32_t)blk);
-        atomicMax(&a.linkStat[4], (uint32_t)cap);          // the largest such block sizes the second pass's scratch
+    __shared__ uint32_t sh[4];
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) { sh[0] = 0u; sh[1] = 0xffffffffu; sh[2] = 0u; sh[3] = 0u; }
+    __syncthreads();
+    const int blk = (int)(blockIdx.x * 1024u) + tid;
+    bool bad = false;
+    int cap = 0;
+    if (blk < a.nBlocks && is_codec_error(a.result[blk])) {
+        const uint8_t *data = nullptr;
+        int compLen = 0;
+        bad = read_block_header(a, blk, data, compLen, cap) == 0;     // (a codec error means the header was accepted)
     }
+    const uint64_t m = __ballot(bad);
+    if (m) {
+        // wave-level first: one lane per wave talks to LDS
+        int wcap = bad ? cap : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wcap = max(wcap, __shfl_xor(wcap, d));
+        if ((tid & 63) == 0) {
+            const int w0 = blk;                                        // first lane's block
+            atomicAdd(&sh[0], (uint32_t)__builtin_popcountll(m));
+            atomicMin(&sh[1], (uint32_t)(w0 + (int)__builtin_ctzll(m)));
+            atomicMax(&sh[2], (uint32_t)(w0 + 63 - (int)__builtin_clzll(m)));
+            atomicMax(&sh[3], (uint32_t)wcap);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && sh[0]) {
+        atomicAdd(&a.linkStat[0], sh[0]);
+        atomicMin(&a.linkStat[1], sh[1]);
+        atomicMax(&a.linkStat[2], sh[2]);
+        atomicMax(&a.linkStat[4], sh[3]);          // the largest such block sizes the second pass's scratch
+    }
+}
+static void launch_link_stat(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.linkStat && a.nBlocks > 0)
+        hipLaunchKernelGGL(k_link_stat, dim3((unsigned)((a.nBlocks + 1023) / 1024)), dim3(1024), 0, s, a);
 }
 
 // One wavefront per block, 4 blocks per 256-thread workgroup.
@@ -72,7 +109,7 @@ __global__ __launch_bounds__(256, 6) void k_decode_seq(DecodeArgs a)
     if (r == 0)
         r = decode_block_seq(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                              a.framed + a.framedLen);
-    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r, cap); }
+    if (lane_id() == 0) a.result[blk] = r;
 }
 
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
@@ -80,6 +117,7 @@ void launch_decode_seq(const DecodeArgs &a, hipStream_t s)
     if (a.nBlocks <= 0) return;
     const unsigned grid = (unsigned)((a.nBlocks + 3) / 4);
     hipLaunchKernelGGL(k_decode_seq, dim3(grid), dim3(256), 0, s, a);
+    launch_link_stat(a, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -473,7 +511,7 @@ __global__ PAR_OCC void k_decode_par(DecodeArgs a, unsigned long long *stats)
     if (r == 0)
         r = decode_block_par<STATS, false>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
                                     a.framed + a.framedLen, lds, stats);
-    if (lane_id() == 0) { a.result[blk] = r; note_link_failure(a, blk, r, cap); }
+    if (lane_id() == 0) a.result[blk] = r;
 }
 
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s)
@@ -483,6 +521,7 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
         hipLaunchKernelGGL(k_decode_par<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
     else
         hipLaunchKernelGGL(k_decode_par<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+    launch_link_stat(a, s);
 }
 
 // Linked streams (reference semantics of LZ4_decompress_safe_continue with every
@@ -556,10 +595,11 @@ __global__ __launch_bounds__(64, 4) void k_decode_tolerant(DecodeArgs a)
     if (read_block_header(a, blk, data, compLen, cap) == 0 && cap <= TOL_MAX_BLOCK) {
         // one list region (TOL_LIST_CAP entries) per 64 KiB of capacity, taken in one piece
         const unsigned need = (unsigned)max(1, (cap + RPL_HALF - 1) / RPL_HALF);
-        unsigned got = 0;
-        if (lane_id() == 0) got = atomicAdd(a.tolCounter, need);
-        got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-        if (got + need <= (unsigned)a.tolRegions) {
+        // The regions of a launch are handed out by position: block segFirst + i owns [i * tolPer, (i + 1) * tolPer), tolPer
+        // = what the largest dependent block of the call needs.  (Round 3 drew them from one counter: an atomic with a
+        // returned value per block, all on one address, in front of every block's decode.)
+        const unsigned got = (unsigned)(blk - a.segFirst) * (unsigned)a.tolPer;
+        if (need <= (unsigned)a.tolPer && got + need <= (unsigned)a.tolRegions) {
             region = (int)got;
             for (int i = lane_id(); i < 128; i += LZ4_WAVE) lds.t.taint[i] = 0;
             if (lane_id() == 0) {
