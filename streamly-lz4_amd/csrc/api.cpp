@@ -660,6 +660,21 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         link_scratch_release(c);          // the first pass is in flight on linkBuf: the next linked call must be ordered behind it
         return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
     }
+    // Few dependent blocks, in short runs (stat[5] = longest run of blocks without output): every run is walked by a
+    // wave of its own with the exact decoder and its dictionary; no lists, no pointers.  MI355LZ4_LINKED_RUNS = longest run
+    // taken this way (default 4; 0 = never; the tests force it for whole streams).
+    {
+        const char *envRuns = getenv("MI355LZ4_LINKED_RUNS");
+        const unsigned runMax = envRuns ? (unsigned)atoi(envRuns) : 4u;
+        const bool plain = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS");
+        if (!streamFirst && !a.asyncGate && !splitOk && !deferEnd && runMax > 0 && stat[5] >= 1 && stat[5] <= runMax &&
+            (envRuns || plain)) {
+            a.segFirst = first; a.segEnd = last + 1;
+            launch_linked_runs(a, c->stream);
+            link_scratch_release(c);
+            return check_launch("decode launch");
+        }
+    }
     // Lists of deferred matches for up to POOL_BLOCKS dependent blocks at a time (64 KiB each: one byte per output
     // byte) and source pointers for up to PTR_BLOCKS of them (four bytes per output byte); without the lists the
     // blocks are walked one after the other.  (Read per call: the tests shrink both to reach every seam.)

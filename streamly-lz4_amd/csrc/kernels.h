@@ -89,6 +89,7 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fet
 void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: the fetch of block a.onlyBlk alone; PtrCtl::lastOpen tells whether it is complete
 size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
+void launch_linked_runs(const DecodeArgs &a, hipStream_t s);      // one stream, short runs of dependent blocks: one wave per run, exact decoder with dictionary
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();
 void launch_encode(const EncodeArgs &a, bool bigBlocks, hipStream_t s);   // bigBlocks: some block is above 64 KiB

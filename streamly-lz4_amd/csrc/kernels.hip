@@ -56,6 +56,7 @@ __device__ __forceinline__ bool is_codec_error(int r) { return r < 0 && r > -0x7
 // is done.  (Round 3 had every failing block add to these five words itself: four atomics per block on ONE cache line,
 // 16 384 of them for a reference-written stream of 4096 blocks, which cost the standalone pass 0.33 of its 0.38 ms --
 // the blocks themselves give up at their first sequence.)  One workgroup per 1024 blocks, one set of atomics each.
+#define LINK_RUN_CAP 64
 __global__ __launch_bounds__(1024) void k_link_stat(DecodeArgs a)
 {
     __shared__ uint32_t sh[4];
@@ -83,6 +84,14 @@ __global__ __launch_bounds__(1024) void k_link_stat(DecodeArgs a)
             atomicMax(&sh[2], (uint32_t)(w0 + 63 - (int)__builtin_clzll(m)));
             atomicMax(&sh[3], (uint32_t)wcap);
         }
+    }
+    // linkStat[5] = the longest run of consecutive blocks that produced no output (capped at LINK_RUN_CAP + 1): how long
+    // the serial part is when every run is walked by a wave of its own (k_decode_fixup_runs).  Only a run's first block
+    // counts it.
+    if (blk < a.nBlocks && a.result[blk] <= 0 && (blk == 0 || a.result[blk - 1] > 0)) {
+        int n = 1;
+        while (n <= LINK_RUN_CAP && blk + n < a.nBlocks && a.result[blk + n] <= 0) n++;
+        atomicMax(&a.linkStat[5], (uint32_t)n);
     }
     __syncthreads();
     if (tid == 0 && sh[0]) {
@@ -564,6 +573,52 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
         if (r > 0) { dict = dst; dictLen = (uint32_t)r; }          // :2331-2333, :2353-2355
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     }
+}
+
+// One stream in which FEW blocks need their dictionary (a reference-written stream of data whose matches rarely reach
+// back into the block before: 229 of 16 384 blocks of the bench's lzsynth sample): every maximal run of blocks without
+// output is walked by a wavefront of its own with the exact lane-parallel decoder and the previous output as external
+// dictionary -- the runs are independent of each other because the block in front of a run is final.  The pointer pass
+// would write and chase four bytes of pointer per output byte of the whole SPAN between the first and the last dependent
+// block for them (2 ms for that sample; this: one block's latency per block of the longest run).  Chosen by the host
+// when the longest run is short (linkStat[5]); same dictionary rules as k_decode_fixup_regions (:2331-2333, :2347-2355).
+__global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int blk = a.segFirst + (int)blockIdx.x;
+    if (blk >= a.segEnd || uni(a.result[blk]) > 0) return;
+    // a run starts behind a block with output (or at the range's first block)
+    if (blk != a.segFirst && uni(a.result[blk - 1]) <= 0) return;
+    const uint8_t *dict = nullptr;
+    uint32_t dictLen = 0;
+    if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
+    for (int j = blk - 1; j >= -a.lookBack; j--) {
+        const int rj = uni(a.result[j]);
+        if (rj > 0) { dict = a.out + a.outOff[j]; dictLen = (uint32_t)rj; break; }
+    }
+    for (int f = blk; f < a.segEnd; f++) {
+        int r = uni(a.result[f]);
+        if (r > 0) break;                                           // the run is over
+        uint8_t *dst = a.out + a.outOff[f];
+        if (is_codec_error(r) && dictLen > 0) {
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, f, data, compLen, cap);
+            if (r == 0)
+                r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed,
+                                                  a.framed + a.framedLen, lds, nullptr);
+            r = uni(r);
+            if (lane_id() == 0) a.result[f] = r;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
+    }
+}
+
+void launch_linked_runs(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n > 0) hipLaunchKernelGGL(k_decode_fixup_runs, dim3((unsigned)n), dim3(64), 0, s, a);
 }
 
 // Single stream (streamFirst == null): only REGIONS need the serial walk.  A region is a maximal run of

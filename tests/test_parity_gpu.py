@@ -624,7 +624,9 @@ def _decode_streams(engine, frs, linked_mode):
 # exact decoder block after block.  The environment picks which ones a call may use and how many dependent
 # blocks a segment holds, so that every path and every segment seam sees the same tests.
 LINKED_VARIANTS = {
-    "default": {},
+    "default": {},                                                 # runs of up to 4 dependent blocks: one wave per run (k_decode_fixup_runs)
+    "runs_forced": {"MI355LZ4_LINKED_RUNS": "100000"},             # every run, however long, through the run walker
+    "no_runs": {"MI355LZ4_LINKED_RUNS": "0"},                      # ... and never: short streams through the pointer pass
     "segments_of_3": {"MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
     "pointer_pass_forced": {"MI355LZ4_LINKED_PTR": "1"},          # (many short streams would be walked otherwise)
     "pointer_segments_of_2": {"MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_PTR_BLOCKS": "2"},
