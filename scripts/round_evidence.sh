@@ -35,5 +35,10 @@ python3 scripts/host_api_rate.py > "$E/host_api_rate.jsonl" 2>/dev/null
 rm -f gpurun_out/linked_rate.json; python3 -m pytest tests/test_linked_rate_gpu.py -q -m gpu > "$E/linked_rate_test.log" 2>&1
 rm -f gpurun_out/linked_rate.json.prev; cp gpurun_out/linked_rate.json "$E/linked_streams_rate.jsonl" 2>/dev/null
 scripts/kernel_resources.sh > "$E/kernel_resources.txt" 2>&1
+# issue rate of integer vector instructions (section 0 of DESIGN.md prices the decoder with these)
+[ -x scripts/micro/valu_rate.bin ] && scripts/micro/valu_rate.bin > "$E/valu_issue_rate.txt" 2>&1
+# `python3 bench.py --gpus 2` on its own (the script starts its ranks as a child process), rehearsed on this one GPU over gloo
+BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo timeout 900 python3 bench.py --gpus 2 --steps 3 --warmup 1 --blocks 4096 \
+    > "$E/bench_n2_selflaunch_rehearsal.json" 2> "$E/bench_n2_selflaunch_rehearsal.err"; echo "rc=$?" >> "$E/bench_n2_selflaunch_rehearsal.err"
 grep -l "Memory access fault" "$E"/* && exit 9
 ls -la "$E" | tail -40
