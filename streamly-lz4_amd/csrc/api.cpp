@@ -1435,38 +1435,77 @@ static mi355lz4_ctx *legacy_engine()
     return g_engine;
 }
 
-struct LZ4_stream_u { uint32_t magic; };
+// One call = one block.  Since round 4 a call is ONE host-to-device copy (staged in page-locked memory), ONE kernel
+// launch, ONE device-to-host copy (the output with its size word behind it) and ONE synchronisation.  The decoder keeps
+// the previous block's output where it was decoded -- the next call decodes into the other of two buffers -- so the
+// dictionary is never copied.  (Round 3: a heap-allocated frame or output vector, three or four synchronisations and a
+// device-to-device copy of the dictionary per block.)  Still one PCIe round trip per block: compatibility, not speed.
+struct LegacyBuf { void *p = nullptr; size_t cap = 0; };
+static bool legacy_dev(LegacyBuf &b, size_t n)
+{
+    if (n <= b.cap) return true;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    if (hipMalloc(&b.p, n * 2) != hipSuccess) { b.p = nullptr; return false; }
+    b.cap = n * 2;
+    return true;
+}
+static bool legacy_pin(LegacyBuf &b, size_t n)
+{
+    if (n <= b.cap) return true;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    if (hipHostMalloc(&b.p, n * 2, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return false; }
+    b.cap = n * 2;
+    return true;
+}
+struct LZ4_stream_u {
+    uint32_t magic;
+    LegacyBuf inDev, slotDev, inPin, outPin;
+};
 struct LZ4_streamDecode_u {
     uint32_t magic;
-    void *dictDev;       // last <= 64 KiB of the previous block's output, on the device
+    const uint8_t *dictDev;       // last <= 64 KiB of the previous block's output, inside outDev[1 - cur]
     uint32_t dictLen;
-    void *inDev, *outDev, *metaDev;
-    size_t inCap, outCap;
+    int cur;
+    LegacyBuf inDev, outDev[2], inPin, outPin;
 };
+// [blockOff = 0 | outOff = 0 | result | pad] travels in front of the framed block
+#define LEGACY_PRE 32
 
 extern "C" LZ4_stream_t *LZ4_createStream(void)
 {
-    LZ4_stream_u *s = (LZ4_stream_u *)calloc(1, sizeof(LZ4_stream_u));
+    LZ4_stream_u *s = new (std::nothrow) LZ4_stream_u();
     if (s) s->magic = 0x4C5A3443u;
     return (LZ4_stream_t *)s;
 }
-extern "C" int LZ4_freeStream(LZ4_stream_t *s) { free(s); return 0; }
+extern "C" int LZ4_freeStream(LZ4_stream_t *p)
+{
+    LZ4_stream_u *s = (LZ4_stream_u *)p;
+    if (!s) return 0;
+    if (s->inDev.p) (void)hipFree(s->inDev.p);
+    if (s->slotDev.p) (void)hipFree(s->slotDev.p);
+    if (s->inPin.p) (void)hipHostFree(s->inPin.p);
+    if (s->outPin.p) (void)hipHostFree(s->outPin.p);
+    delete s;
+    return 0;
+}
 
 extern "C" LZ4_streamDecode_t *LZ4_createStreamDecode(void)
 {
-    LZ4_streamDecode_u *s = (LZ4_streamDecode_u *)calloc(1, sizeof(LZ4_streamDecode_u));
-    if (s) s->magic = 0x4C5A3444u;
+    LZ4_streamDecode_u *s = new (std::nothrow) LZ4_streamDecode_u();
+    if (s) { s->magic = 0x4C5A3444u; s->dictDev = nullptr; s->dictLen = 0; s->cur = 0; }
     return (LZ4_streamDecode_t *)s;
 }
 extern "C" int LZ4_freeStreamDecode(LZ4_streamDecode_t *p)
 {
     LZ4_streamDecode_u *s = (LZ4_streamDecode_u *)p;
     if (!s) return 0;
-    if (s->dictDev) hipFree(s->dictDev);
-    if (s->inDev) hipFree(s->inDev);
-    if (s->outDev) hipFree(s->outDev);
-    if (s->metaDev) hipFree(s->metaDev);
-    free(s);
+    if (s->inDev.p) (void)hipFree(s->inDev.p);
+    for (int k = 0; k < 2; k++) if (s->outDev[k].p) (void)hipFree(s->outDev[k].p);
+    if (s->inPin.p) (void)hipHostFree(s->inPin.p);
+    if (s->outPin.p) (void)hipHostFree(s->outPin.p);
+    delete s;
     return 0;
 }
 
@@ -1477,24 +1516,36 @@ extern "C" int LZ4_compressBound(int inputSize) { return mi355lz4_compress_bound
 extern "C" int LZ4_compress_fast_continue(LZ4_stream_t *streamPtr, const char *src, char *dst, int srcSize,
                                           int dstCapacity, int acceleration)
 {
-    (void)streamPtr;
+    LZ4_stream_u *s = (LZ4_stream_u *)streamPtr;
     mi355lz4_ctx *c = legacy_engine();
-    if (!c || srcSize < 0 || dstCapacity <= 0 || !dst) return 0;
-    const uint8_t *srcs[1] = {(const uint8_t *)src};
-    int32_t lens[1] = {srcSize};
-    std::vector<uint8_t> tmp((size_t)mi355lz4_compress_bound(srcSize) + 8);
-    size_t outLen = 0;
-    int32_t st = 0;
+    if (!c || !s || srcSize < 0 || dstCapacity <= 0 || !dst || (!src && srcSize > 0)) return 0;
+    if ((unsigned)srcSize > (unsigned)MI355LZ4_MAX_INPUT_SIZE) return 0;          // cbits/lz4.c:1254
     std::lock_guard<std::mutex> lk(g_engineMu);
-    if (mi355lz4_compress_batch(c, srcs, lens, 1, acceleration, 4, tmp.data(), tmp.size(), &outLen, nullptr, &st) != MI355LZ4_OK)
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    const size_t stride = mi355lz4_slot_stride(srcSize, 4);
+    if (!legacy_dev(s->inDev, (size_t)srcSize + 16) || !legacy_dev(s->slotDev, stride + 16) ||
+        !legacy_pin(s->inPin, (size_t)srcSize + 16) || !legacy_pin(s->outPin, stride + 16))
         return 0;
+    if (srcSize) {
+        memcpy(s->inPin.p, src, (size_t)srcSize);
+        if (hipMemcpyAsync(s->inDev.p, s->inPin.p, (size_t)srcSize, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 0;
+    }
+    int32_t *lenDev = (int32_t *)((uint8_t *)s->slotDev.p + stride);
+    if (encode_device(c, (const uint8_t *)s->inDev.p, nullptr, nullptr, (uint64_t)srcSize, srcSize, 1, acceleration, 4,
+                      (uint8_t *)s->slotDev.p, stride, lenDev, 0) != MI355LZ4_OK)
+        return 0;
+    if (hipMemcpyAsync(s->outPin.p, s->slotDev.p, stride + 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    int32_t framed = 0;
+    memcpy(&framed, (const uint8_t *)s->outPin.p + stride, 4);
+    const int st = framed - 4;
     if (st <= 0 || st > dstCapacity) return 0;   // limitedOutput: cbits/lz4.c:1024-1027
-    memcpy(dst, tmp.data() + 4, (size_t)st);
+    memcpy(dst, (const uint8_t *)s->outPin.p + 4, (size_t)st);
     return st;
 }
 
 // Linked semantics of cbits/lz4.c:2322-2359 for separately allocated blocks: the
-// previous block's output is kept on the device as the external dictionary.
+// previous block's output stays on the device as the external dictionary.
 extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *src, char *dst, int srcSize,
                                             int dstCapacity)
 {
@@ -1503,37 +1554,53 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     if (!c || !s) return -1;
     if (!src) return -1;                                          // cbits/lz4.c:1752
     if (srcSize < 0 || dstCapacity < 0) return -1;
+    if (srcSize == 0) return -1;                                   // cbits/lz4.c:1787 (and :1781 for cap==0)
     std::lock_guard<std::mutex> lk(g_engineMu);
     if (hipSetDevice(c->device) != hipSuccess) return -1;
-    const size_t inNeed = (size_t)srcSize + 16, outNeed = (size_t)dstCapacity + 16;
-    if (s->inCap < inNeed) { if (s->inDev) hipFree(s->inDev); s->inDev = nullptr; if (hipMalloc(&s->inDev, inNeed * 2) != hipSuccess) return -1; s->inCap = inNeed * 2; }
-    if (s->outCap < outNeed) { if (s->outDev) hipFree(s->outDev); s->outDev = nullptr; if (hipMalloc(&s->outDev, outNeed * 2) != hipSuccess) return -1; s->outCap = outNeed * 2; }
-    if (!s->metaDev && hipMalloc(&s->metaDev, 64) != hipSuccess) return -1;
-    if (!s->dictDev && hipMalloc(&s->dictDev, 65536) != hipSuccess) return -1;
-
-    // synthesize a one-block headerKind-4 frame around the payload
-    std::vector<uint8_t> framed((size_t)srcSize + 4);
-    framed[0] = (uint8_t)srcSize; framed[1] = (uint8_t)(srcSize >> 8);
-    framed[2] = (uint8_t)(srcSize >> 16); framed[3] = (uint8_t)(srcSize >> 24);
-    if (srcSize) memcpy(framed.data() + 4, src, (size_t)srcSize);
-    uint64_t meta[2] = {0, 0};   // blockOff[0], outOff[0]
-    int32_t res = -1;
-    if (srcSize == 0) return -1;                                   // cbits/lz4.c:1787 (and :1781 for cap==0)
-    if (hipMemcpyAsync(s->inDev, framed.data(), framed.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
-    if (hipMemcpyAsync(s->metaDev, meta, 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-    int32_t *resDev = (int32_t *)((uint8_t *)s->metaDev + 32);
-    if (decode_device(c, (const uint8_t *)s->inDev, framed.size(), (const uint64_t *)s->metaDev, 1, 4, dstCapacity, 1,
-                      (uint8_t *)s->outDev, (const uint64_t *)s->metaDev + 1, nullptr, resDev,
-                      s->dictLen ? (const uint8_t *)s->dictDev : nullptr, s->dictLen) != MI355LZ4_OK)
+    const size_t inBytes = LEGACY_PRE + 4 + (size_t)srcSize;
+    const size_t outPad = ((size_t)dstCapacity + 15) & ~(size_t)15;      // the result word sits behind the output
+    LegacyBuf &outDev = s->outDev[s->cur];
+    if (!legacy_dev(s->inDev, inBytes + 16) || !legacy_dev(outDev, outPad + 32) || !legacy_pin(s->inPin, inBytes) ||
+        !legacy_pin(s->outPin, outPad + 16))
         return -1;
-    if (hipMemcpyAsync(&res, resDev, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    // (growing outDev[cur] cannot move the dictionary: that lies in the OTHER buffer)
+    uint8_t *hp = (uint8_t *)s->inPin.p;
+    memset(hp, 0, LEGACY_PRE);
+    const int32_t preset = s->dictLen ? -1 : 0;                    // a codec error: "this block wants its dictionary"
+    memcpy(hp + 16, &preset, 4);
+    hp[LEGACY_PRE + 0] = (uint8_t)srcSize; hp[LEGACY_PRE + 1] = (uint8_t)(srcSize >> 8);
+    hp[LEGACY_PRE + 2] = (uint8_t)(srcSize >> 16); hp[LEGACY_PRE + 3] = (uint8_t)(srcSize >> 24);
+    memcpy(hp + LEGACY_PRE + 4, src, (size_t)srcSize);
+    if (hipMemcpyAsync(s->inDev.p, hp, inBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    int32_t *resDev = (int32_t *)((uint8_t *)outDev.p + outPad);
+    DecodeArgs a;
+    a.framed = (const uint8_t *)s->inDev.p + LEGACY_PRE; a.framedLen = 4 + (uint64_t)srcSize;
+    a.blockOff = (const uint64_t *)s->inDev.p; a.nBlocks = 1;
+    a.headerKind = 4; a.fixedUncomp = dstCapacity; a.linked = 1;
+    a.out = (uint8_t *)outDev.p; a.outOff = (const uint64_t *)s->inDev.p + 1; a.outCap = nullptr; a.result = resDev;
+    a.dict0 = s->dictLen ? s->dictDev : nullptr; a.dict0Len = s->dictLen;
+    a.streamFirst = nullptr; a.nStreams = 0; a.lookBack = 0;
+    a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
+    a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
+    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1;
+    if (s->dictLen) {
+        // the exact decoder with the dictionary in force, at once (a block that does not reach back decodes the same)
+        if (hipMemcpyAsync(resDev, (const uint8_t *)s->inDev.p + 16, 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;
+        launch_linked_runs(a, c->stream);
+    } else {
+        launch_decode_par(a, nullptr, c->stream);
+    }
+    if (check_launch("decode launch") != MI355LZ4_OK) return -1;
+    if (hipMemcpyAsync(s->outPin.p, outDev.p, outPad + 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    int32_t res = -1;
+    memcpy(&res, (const uint8_t *)s->outPin.p + outPad, 4);
     if (res <= 0) return res;                                      // :2331 / :2353: context unchanged
-    if (hipMemcpyAsync(dst, s->outDev, (size_t)res, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (res > dstCapacity) return -1;
+    memcpy(dst, s->outPin.p, (size_t)res);
     const uint32_t keep = (res > 65536) ? 65536u : (uint32_t)res;
-    if (hipMemcpyAsync(s->dictDev, (const uint8_t *)s->outDev + ((size_t)res - keep), keep, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    s->dictDev = (const uint8_t *)outDev.p + ((size_t)res - keep);
     s->dictLen = keep;
+    s->cur ^= 1;
     return res;
 }

@@ -52,7 +52,9 @@ namespace lz4dev {
 #define PAR_BATCH_OUT 2560  // max output bytes of one batch
 #endif
 #ifndef PAR_FAR_WIDE
-#define PAR_FAR_WIDE 1      // far matches: one 16-byte request per lane instead of two requests per length class
+#define PAR_FAR_WIDE 0      // far matches: 1 = one 16-byte request per lane instead of two requests per length class.  Measured
+                            // (round 4): vector-memory reads -50 % (text -56 %), rate unchanged, but FETCH_SIZE +5 % on text (a
+                            // 16-byte request crosses more 32-byte sectors than an 8-byte one): off
 #endif
 #ifndef PAR_RANK
 #define PAR_RANK 1          // dependency masks from a bit vector of sequence starts (rank queries) instead of binary searches

@@ -14,6 +14,7 @@ void launch_linked_resolve_b(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUN
 void launch_linked_fetch_block(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 size_t ptr_ctl_last_open_offset() { return 0; }
 void launch_longest_stream(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_linked_runs(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 size_t tol_region_bytes() { return 65536; }
 void launch_encode(const EncodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_encode_seg(const EncodeSegArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
