@@ -151,6 +151,7 @@ struct mi355lz4_ctx {
     int linkedCompress = 0;                 // compress calls treat their blocks as consecutive blocks of one stream
     // workspaces of the host-buffer API (grown on demand, reused across calls)
     DevBuf in, slots, dense, out, offA, offB, lenA, lenB, res, scratch;
+    DevBuf tokBuf;                          // decoder variant 3: token lists
     DevBuf tolPool, tolMeta;                // deferred-copy decode of a long linked stream (linked_replay.hpp)
     DevBuf linkBuf, ptrBuf, pinStat;        // ... its failure count, control block and source pointers (linked_ptr.hpp)
     DevBuf pinIn, pinOut;   // pinned host staging
@@ -324,7 +325,7 @@ extern "C" void mi355lz4_destroy(mi355lz4_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->in, &c->slots, &c->dense, &c->out, &c->offA, &c->offB, &c->lenA, &c->lenB, &c->res, &c->scratch,
-                      &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf, &c->seg[0].b, &c->seg[1].b, &c->seg[2].b, &c->seg[3].b})
+                      &c->tolPool, &c->tolMeta, &c->linkBuf, &c->ptrBuf, &c->seg[0].b, &c->seg[1].b, &c->seg[2].b, &c->seg[3].b, &c->tokBuf})
         dev_release(*b);
     if (c->linkEvent) hipEventDestroy(c->linkEvent);
     pin_release(c->pinStat);
@@ -371,7 +372,7 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 2) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -620,6 +621,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
+    a.tokList = nullptr; a.tokCnt = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -632,7 +634,12 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
-    else
+    else if (c->decoder == 3 && dev_reserve(c->tokBuf, (size_t)(framedLen >> 1) + 192 + ((size_t)nBlocks + 1) * sizeof(int32_t)) == 0) {
+        // experiment: the parse as a pass of its own (token lists), then the list-driven decoder
+        a.tokCnt = (int32_t *)c->tokBuf.p;
+        a.tokList = (uint8_t *)c->tokBuf.p + ((((size_t)nBlocks + 1) * sizeof(int32_t) + 63) & ~(size_t)63);
+        launch_decode_tok(a, c->stream);
+    } else
         launch_decode_par(a, c->stats, c->stream);
     if (!linked) return check_launch("decode launch");
     // Linked streams.  Whether there is a second pass at all, and over which blocks, is decided here: the
@@ -1582,7 +1589,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.streamFirst = nullptr; a.nStreams = 0; a.lookBack = 0;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
-    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1;
+    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr;
     if (s->dictLen) {
         // the exact decoder with the dictionary in force, at once (a block that does not reach back decodes the same)
         if (hipMemcpyAsync(resDev, (const uint8_t *)s->inDev.p + 16, 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;

@@ -128,11 +128,18 @@ enum { PS_BATCHES, PS_SEQS, PS_ROUNDS, PS_MATCH_ITERS, PS_LIT_ITERS, PS_HANDOVER
 // TOL: tolerant (deferred-copy) decode of a block of a linked stream without its dictionary, see TolCtx in
 // decode_seq.hpp: matches that start before the block, or whose source touches a tainted granule, are
 // recorded in tol->list instead of being copied.
-template <bool STATS, bool DICT, bool TOL = false>
+// LIST: the token positions of a batch come from a list made by a separate pass (kernels.hip, k_walk_tokens: one LANE per
+// block walks the token chain, which costs a fraction of finding 64 tokens at once by speculation) instead of steps 2-3.
+// list[k] = compressed bytes of sequence k (0 = not known from here on), listLen entries.  The list is a HINT: every
+// position taken from it is checked against the successor the lane in front computes from the token bytes themselves, so
+// a wrong list costs time, never correctness; from the first disagreement on the block falls back to steps 2-3.
+template <bool STATS, bool DICT, bool TOL = false, bool LIST = false>
 __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict,
                                 uint32_t dictLen, const uint8_t *bufLo, const uint8_t *bufHi, ParLds &L,
-                                unsigned long long *stats, TolCtx *tol = nullptr)
+                                unsigned long long *stats, TolCtx *tol = nullptr, const uint8_t *list = nullptr,
+                                int listLen = 0)
 {
+    int li = 0;                            // LIST: index of the sequence that starts at ip
     uint32_t sc[PS_COUNT];                 // wave-uniform (kept in scalar registers)
     uint32_t tmark = 0;
     if (STATS) {
@@ -248,13 +255,27 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             }
             lap(PS_T_WINDOW);
 
+            uint32_t c2, absorb;
+            bool fromList = false;
+            if (LIST && li < listLen) {
+                // ---------------- 2'. token positions from the list ----------------
+                fromList = true;
+                absorb = 2u * (uint32_t)max(inLim, 0);
+                const int k = li + lane;
+                const uint32_t d = (k < listLen) ? (uint32_t)as_global(list)[k] : 0u;
+                const uint64_t zm = __ballot(d == 0u);                       // lanes up to the first unknown length have a position
+                const int known = zm ? (int)__builtin_ctzll(zm) : LZ4_WAVE - 1;
+                const int incl0 = par_scan_incl((int)d);
+                c2 = (lane <= known) ? 2u * (uint32_t)(wofs + incl0 - (int)d) : absorb;
+                c2 = min(c2, absorb);
+            } else {
             // ---------------- 2. speculative parse (registers only) ----------------
             uint32_t J[8];
             // Two nodes per instruction (16-bit halves, v_pk_*).  The absorbing state is the node behind the last one that
             // may be a token, nodeLim + 1: every successor beyond nodeLim is clamped to it, its own included (a successor
             // lies at least three bytes on), so no comparison is needed; for nodeLim = PAR_NODES - 1 that is the extra
             // entry behind the table.
-            const uint32_t absorb = 2u * ((uint32_t)min(inLim, PAR_NODES - 1) + 1u);
+            absorb = 2u * ((uint32_t)min(inLim, PAR_NODES - 1) + 1u);
             {
                 typedef unsigned short par_h2 __attribute__((ext_vector_type(2)));
                 const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
@@ -286,7 +307,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             lap(PS_T_SPEC);
 
             // ---------------- 3. chain: sequence r -> lane r ----------------
-            uint32_t c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
+            c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
             // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
             // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
             // one 8-lane gather per group instead of two more squarings of all 512 nodes.
@@ -340,6 +361,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     if (lane >= G * g && lane < G * g + G) c2 = (uint32_t)sh;
                 }
             }
+            }
             lap(PS_T_CHAIN);
 
             // ---------------- 4. decode own sequence, place it ----------------
@@ -357,6 +379,13 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const uint32_t ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u);
             const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u);
             bool ok = has && !(is15 && b1 == 255u) && !(mlx && b2 == 255u) && (int)nxt <= inLim && off16 != 0;
+            bool listBad = false;
+            if (LIST && fromList) {
+                // the list is a hint: my position must be where the sequence in front of me ends
+                const uint32_t prevNxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                listBad = has && lane > 0 && prevNxt != cc;
+                ok = ok && !listBad;
+            }
             const int len = ok ? (int)(lit + ml) : 0;
             const int incl = par_scan_incl(len);
             const int outEnd = op + incl;
@@ -369,6 +398,11 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                   (TOL && spos < 0));
             const uint64_t okm = __ballot(ok);
             const int nseq = (~okm) ? (int)__builtin_ctzll(~okm) : LZ4_WAVE;
+            if (LIST && fromList) {
+                // a disagreement at the lane that ended the batch: the list is not this block's chain from here on
+                if (nseq < LZ4_WAVE && ((__ballot(listBad) >> nseq) & 1ull)) listLen = 0;
+                li += nseq;
+            }
             lap(PS_T_DECODE);
             if (STATS) { sc[PS_BATCHES]++; sc[PS_SEQS] += (unsigned)nseq; if (nseq == LZ4_WAVE) sc[PS_FULL]++; }
             if (nseq == 0) break;                            // not a plain interior sequence: slow path below
@@ -739,6 +773,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
         r = uni(r);
         if (r != SEQ_CONTINUE) { publish(); return r; }
         ip = uni(st.ip); op = uni(st.op);                 // read back through memory: tell the compiler they are uniform
+        if (LIST) li += 1;                                // (one sequence went through the sequential decoder)
         // Nothing lane-private has to survive the call: the lane id is re-read (an opaque definition, so that
         // the values derived from it are rebuilt instead of being kept in registers across the call) and the
         // window is fetched again.  decode_seq_run clobbers v0..v79; every VGPR that lives across the call

@@ -533,6 +533,72 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
     launch_link_stat(a, s);
 }
 
+// ---- token lists: the parse as a pass of its own (experiment of round 4) ----
+// One LANE per block walks the block's token chain (cbits/lz4.c:1801-1854: token, literal length, offset, match length)
+// and writes the compressed size of every sequence as one byte; 0 ends the list (a length that does not fit a byte, a
+// 255-run, or the end of the block's plain part).  This first form reads the stream byte by byte from global memory.
+__global__ __launch_bounds__(64) void k_walk_tokens(DecodeArgs a)
+{
+    const int blk = (int)(blockIdx.x * 64u + threadIdx.x);
+    if (blk >= a.nBlocks) return;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int n = 0;
+    if (read_block_header(a, blk, data, compLen, cap) == 0) {
+        const LZ4_GLOBAL uint8_t *p = as_global(data);
+        LZ4_GLOBAL uint8_t *out = as_global(a.tokList + (a.blockOff[blk] >> 1));
+        const int limit = (int)((a.blockOff[blk + 1] - a.blockOff[blk]) >> 1) - 1;
+        int ip = 0;
+        while (n < limit) {
+            const int tp = ip;
+            if (ip + 1 > compLen) break;
+            const uint32_t t = p[ip++];
+            uint32_t lit = t >> 4;
+            if (lit == 15u) {
+                if (ip >= compLen) break;
+                const uint32_t b = p[ip++];
+                if (b == 255u) break;
+                lit += b;
+            }
+            ip += (int)lit;
+            if (ip + 2 > compLen) break;                         // the last sequence has no match: not listed
+            ip += 2;
+            if ((t & 15u) == 15u) {
+                if (ip >= compLen) break;
+                const uint32_t b = p[ip++];
+                if (b == 255u) break;
+            }
+            const int d = ip - tp;
+            if (d > 255) break;
+            out[n++] = (uint8_t)d;
+        }
+    }
+    a.tokCnt[blk] = n;
+}
+
+template <bool STATS>
+__global__ PAR_OCC void k_decode_tok(DecodeArgs a, unsigned long long *stats)
+{
+    __shared__ ParLds lds;
+    const int blk = (int)blockIdx.x;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = read_block_header(a, blk, data, compLen, cap);
+    if (r == 0)
+        r = decode_block_par<STATS, false, false, true>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
+                                                        a.framed + a.framedLen, lds, stats, nullptr,
+                                                        a.tokList + (a.blockOff[blk] >> 1), uni(a.tokCnt[blk]));
+    if (lane_id() == 0) a.result[blk] = r;
+}
+
+void launch_decode_tok(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    hipLaunchKernelGGL(k_walk_tokens, dim3((unsigned)((a.nBlocks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_decode_tok<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, (unsigned long long *)nullptr);
+    launch_link_stat(a, s);
+}
+
 // Linked streams (reference semantics of LZ4_decompress_safe_continue with every
 // block in its own allocation, cbits/lz4.c:2347-2355): block i may reference the
 // output of the last block before it IN ITS STREAM that decoded to > 0 bytes.  A

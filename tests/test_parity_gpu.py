@@ -27,7 +27,7 @@ def split_blocks(fr, meta=8):
 # --------------------------------------------------------------------------------------------
 # decode: bit-exact vs oracle / golden
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["lzsynth", "text", "random"])
 def test_decode_matches_oracle(engine, oracle, kind, decoder):
     engine.set_decoder(decoder)
@@ -67,7 +67,7 @@ def test_decode_linked_fixture(engine, linked_golden):
     assert blen == [linked_golden["block_len"]] * 4 and sha(out) == linked_golden["raw_sha256"]
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_malformed_codes(engine, golden, decoder):
     """Negative codes -(ip-src)-1 (cbits/lz4.c:2163) equal the reference's, for both decoder kernels."""
     engine.set_decoder(decoder)
@@ -85,7 +85,7 @@ def test_decode_malformed_codes(engine, golden, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
     """Mutated / truncated blocks, batched: every status and every decoded byte equals the oracle's."""
     engine.set_decoder(decoder)
@@ -122,7 +122,7 @@ def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2])
+@pytest.mark.parametrize("decoder", [1, 2, 3])
 def test_decode_huge_length_fields(engine, oracle, decoder):
     """Length fields that are multi-megabyte runs of 0xFF (lengths >= 2^31): same code as the oracle, and
     nothing is written outside the block's output (cbits/lz4.c:1811-1818, 1854-1858, 2064-2065)."""
