@@ -40,7 +40,20 @@
 
 namespace lz4dev {
 
-#define PAR_NODES 512       // speculative token candidates per window (8 per lane)
+#define PAR_NODES 512       // speculative token candidates per window in the default form (8 per lane)
+#ifndef PAR_ADAPT
+#define PAR_ADAPT 1         // nodes per lane chosen per batch from the compressed bytes per sequence of the batch before: 6 or 8
+#endif
+#ifndef PAR_ADAPT6
+#define PAR_ADAPT6 416      // six nodes per lane while 64 sequences of the last batch's size need at most this many compressed bytes
+#endif
+#ifndef PAR_ADAPT10
+#define PAR_ADAPT10 0       // ... or 10 (measured: the lzsynth stream gets 62 instead of 55 sequences into a batch and decodes no faster)
+#endif
+#define PAR_MAXNODES (PAR_ADAPT10 ? 640 : 512)
+#ifndef PAR_SQ
+#define PAR_SQ 3            // squaring rounds: the chain is then followed in groups of 2^PAR_SQ lanes
+#endif
 #define PAR_WIN 1024        // bytes of compressed stream staged per window (16 per lane)
 #ifndef PAR_RING
 #define PAR_RING 6144       // LDS output staging (8.3 KiB of LDS per wave in all: 19 waves per CU)
@@ -68,7 +81,7 @@ namespace lz4dev {
 // the last one that may hold a token (`absorb` in the speculative parse), at most 2*PAR_NODES: the entry behind the table.
 struct __attribute__((aligned(16))) ParLds {
     uint8_t win[PAR_WIN + 32];
-    uint16_t jump[PAR_NODES + 8];
+    uint16_t jump[PAR_MAXNODES + 8];
     uint8_t ring[PAR_RING + 32];
 };
 #define PAR_END (2 * PAR_NODES)
@@ -140,6 +153,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                                 int listLen = 0)
 {
     int li = 0;                            // LIST: index of the sequence that starts at ip
+    int nodesPerLane = 8;                  // PAR_ADAPT: token candidates per lane of the next batch (6, 8 or 10)
     uint32_t sc[PS_COUNT];                 // wave-uniform (kept in scalar registers)
     uint32_t tmark = 0;
     if (STATS) {
@@ -231,7 +245,7 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
     uint4 wnext = fetch_window(wbase);
     bool winStale = true;                                  // L.win does not hold the window at wbase yet
     const uint8_t *jumpB = (const uint8_t *)L.jump;
-    if (lane == 0) L.jump[PAR_NODES] = PAR_END;            // absorbing state
+    // (the absorbing state behind the table is written with every batch's table: its place depends on the nodes per lane)
 
     for (;;) {
         // ================= hot loop: batches of plain interior sequences =================
@@ -269,68 +283,96 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 c2 = (lane <= known) ? 2u * (uint32_t)(wofs + incl0 - (int)d) : absorb;
                 c2 = min(c2, absorb);
             } else {
-            // ---------------- 2. speculative parse (registers only) ----------------
-            uint32_t J[8];
-            // Two nodes per instruction (16-bit halves, v_pk_*).  The absorbing state is the node behind the last one that
-            // may be a token, nodeLim + 1: every successor beyond nodeLim is clamped to it, its own included (a successor
-            // lies at least three bytes on), so no comparison is needed; for nodeLim = PAR_NODES - 1 that is the extra
-            // entry behind the table.
-            absorb = 2u * ((uint32_t)min(inLim, PAR_NODES - 1) + 1u);
-            {
-                typedef unsigned short par_h2 __attribute__((ext_vector_type(2)));
-                const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
-                const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
-                const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xf, 0xf, false);   // next lane's first bytes
-                auto h2 = [](uint32_t x) { par_h2 r; __builtin_memcpy(&r, &x, 4); return r; };
-                auto u32 = [](par_h2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; };
-                const par_h2 one = {1, 1}, lim = h2((absorb >> 1) * 0x00010001u);
-                const uint32_t base3 = (8u * (uint32_t)lane + 3u) * 0x00010001u + 0x00010000u;   // nodes 2p, 2p + 1 of pair p: + 2p
-                uint32_t P[4];
+            // ---------------- 2. speculative parse (registers only) + 3a. squaring rounds ----------------
+            // NL nodes per lane (NL * 64 byte positions of the window are token candidates).  The work of both steps is
+            // proportional to NL -- NL gathers per squaring round -- while a batch takes at most 64 sequences: NL = 8 covers 64
+            // sequences of 8 compressed bytes; text (5.9 bytes per sequence) fills its 64 lanes from 6 nodes per lane, the
+            // lzsynth stream (9.2) needs 10 to get past 55 sequences per batch.  NL follows the batch before (below).
+            auto parse_square = [&](auto NC) {
+                constexpr int NL = decltype(NC)::value;
+                static_assert(NL % 2 == 0 && NL * LZ4_WAVE <= PAR_MAXNODES, "pairs of nodes, table size");
+                uint32_t J[NL];
+                // Two nodes per instruction (16-bit halves, v_pk_*).  The absorbing state is the node behind the last one
+                // that may be a token, nodeLim + 1: every successor beyond nodeLim is clamped to it, its own included (a
+                // successor lies at least three bytes on), so no comparison is needed; for nodeLim = NL * 64 - 1 that is the
+                // extra entry behind the table.
+                absorb = 2u * ((uint32_t)min(inLim, NL * LZ4_WAVE - 1) + 1u);
+                {
+                    typedef unsigned short par_h2 __attribute__((ext_vector_type(2)));
+                    uint32_t w0, w1, w2;                      // my NL bytes and the one behind them, from byte 0 of w0 on
+                    if (NL == 8) {
+                        const uint64_t lo = *(const uint64_t *)&L.win[8 * lane];
+                        w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32);
+                        w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xf, 0xf, false);   // next lane's first bytes
+                    } else {
+                        const uint32_t a = (uint32_t)(NL * lane);
+                        const uint32_t *q = (const uint32_t *)&L.win[a & ~3u];
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+                        const uint32_t sh = a & 3u;
+                        w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                        w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                        w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                    }
+                    auto h2 = [](uint32_t x) { par_h2 r; __builtin_memcpy(&r, &x, 4); return r; };
+                    auto u32 = [](par_h2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; };
+                    const par_h2 one = {1, 1}, lim = h2((absorb >> 1) * 0x00010001u);
+                    const uint32_t base3 = ((uint32_t)(NL * lane) + 3u) * 0x00010001u + 0x00010000u;   // nodes 2p, 2p + 1 of pair p: + 2p
+                    uint32_t P[NL / 2];
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    // tokens of the two nodes and the byte behind each, zero-extended into the halves
-                    const uint32_t ws = (p < 2) ? w0 : w1, wn = (p < 2) ? w1 : w2;
-                    const par_h2 T = h2(__builtin_amdgcn_perm(0u, ws, (p & 1) ? 0x0c030c02u : 0x0c010c00u));
-                    const par_h2 B = h2((p & 1) ? __builtin_amdgcn_perm(wn, ws, 0x0c040c03u) : __builtin_amdgcn_perm(0u, ws, 0x0c020c01u));
-                    const par_h2 lit0 = T >> 4;
-                    const par_h2 ext = (lit0 + one) >> 4;                       // 1 when the literal nibble is 15
-                    const par_h2 term = ext * (B + one) + lit0;                 // 15 + 1 + b1, or the nibble
-                    const par_h2 mlx = ((T & (par_h2){15, 15}) + one) >> 4;     // 1 when the match nibble is 15
-                    const par_h2 nxt = term + mlx + h2(base3 + 0x00020002u * (uint32_t)p);
-                    P[p] = u32(__builtin_elementwise_min(nxt, lim) << 1);
+                    for (int p = 0; p < NL / 2; p++) {
+                        // tokens of the two nodes and the byte behind each, zero-extended into the halves
+                        const uint32_t ws = (p < 2) ? w0 : ((p < 4) ? w1 : w2), wn = (p < 2) ? w1 : w2;
+                        const par_h2 T = h2(__builtin_amdgcn_perm(0u, ws, (p & 1) ? 0x0c030c02u : 0x0c010c00u));
+                        const par_h2 B = h2((p & 1) ? __builtin_amdgcn_perm(wn, ws, 0x0c040c03u) : __builtin_amdgcn_perm(0u, ws, 0x0c020c01u));
+                        const par_h2 lit0 = T >> 4;
+                        const par_h2 ext = (lit0 + one) >> 4;                       // 1 when the literal nibble is 15
+                        const par_h2 term = ext * (B + one) + lit0;                 // 15 + 1 + b1, or the nibble
+                        const par_h2 mlx = ((T & (par_h2){15, 15}) + one) >> 4;     // 1 when the match nibble is 15
+                        const par_h2 nxt = term + mlx + h2(base3 + 0x00020002u * (uint32_t)p);
+                        P[p] = u32(__builtin_elementwise_min(nxt, lim) << 1);
+                    }
+                    uint32_t *tw = (uint32_t *)&L.jump[NL * lane];
+#pragma unroll
+                    for (int p = 0; p < NL / 2; p++) tw[p] = P[p];
+                    if (lane == 0) L.jump[NL * LZ4_WAVE] = (uint16_t)(2 * NL * LZ4_WAVE);   // absorbing state behind the table
+#pragma unroll
+                    for (int p = 0; p < NL / 2; p++) { J[2 * p] = P[p] & 0xffffu; J[2 * p + 1] = P[p] >> 16; }
                 }
-                *(uint4 *)&L.jump[8 * lane] = make_uint4(P[0], P[1], P[2], P[3]);
-#pragma unroll
-                for (int p = 0; p < 4; p++) { J[2 * p] = P[p] & 0xffffu; J[2 * p + 1] = P[p] >> 16; }
-            }
-            wave_fence();
-            lap(PS_T_SPEC);
+                wave_fence();
+                lap(PS_T_SPEC);
 
-            // ---------------- 3. chain: sequence r -> lane r ----------------
-            c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
-            // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
-            // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
-            // one 8-lane gather per group instead of two more squarings of all 512 nodes.
-#ifndef PAR_SQ
-#define PAR_SQ 3            // squaring rounds: the chain is then followed in groups of 2^PAR_SQ lanes
+                // ---------------- 3. chain: sequence r -> lane r ----------------
+                c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
+                // Three squaring rounds give jump^8 for every node and the first 8 token positions (lanes 0..7);
+                // after that only the real chain is followed: lanes 8g..8g+7 are jump^8 of lanes 8(g-1)..8g-1,
+                // one 8-lane gather per group instead of two more squarings of all the nodes.
+#pragma unroll
+                for (int k = 0; k < PAR_SQ; k++) {
+                    const int d = 1 << k;
+                    const int cj = (int)*(const uint16_t *)(jumpB + c2);
+#pragma unroll
+                    for (int j = 0; j < NL; j++) J[j] = (uint32_t)*(const uint16_t *)(jumpB + J[j]);
+                    int sh;
+                    if (k == 0) sh = par_row_shr<1>(cj);
+                    else if (k == 1) sh = par_row_shr<2>(cj);
+                    else if (k == 2) sh = par_row_shr<4>(cj);
+                    else sh = par_row_shr<8>(cj);
+                    if (lane >= d && lane < 2 * d) c2 = (uint32_t)sh;
+                    wave_fence();
+                    uint32_t *tw = (uint32_t *)&L.jump[NL * lane];
+#pragma unroll
+                    for (int p = 0; p < NL / 2; p++) tw[p] = J[2 * p] | (J[2 * p + 1] << 16);
+                    wave_fence();
+                }
+            };
+#if PAR_ADAPT
+            if (nodesPerLane == 6) parse_square(std::integral_constant<int, 6>());
+#if PAR_ADAPT10
+            else if (nodesPerLane == 10) parse_square(std::integral_constant<int, 10>());
 #endif
-#pragma unroll
-            for (int k = 0; k < PAR_SQ; k++) {
-                const int d = 1 << k;
-                const int cj = (int)*(const uint16_t *)(jumpB + c2);
-#pragma unroll
-                for (int j = 0; j < 8; j++) J[j] = (uint32_t)*(const uint16_t *)(jumpB + J[j]);
-                int sh;
-                if (k == 0) sh = par_row_shr<1>(cj);
-                else if (k == 1) sh = par_row_shr<2>(cj);
-                else if (k == 2) sh = par_row_shr<4>(cj);
-                else sh = par_row_shr<8>(cj);
-                if (lane >= d && lane < 2 * d) c2 = (uint32_t)sh;
-                wave_fence();
-                *(uint4 *)&L.jump[8 * lane] =
-                    make_uint4(J[0] | (J[1] << 16), J[2] | (J[3] << 16), J[4] | (J[5] << 16), J[6] | (J[7] << 16));
-                wave_fence();
-            }
+            else
+#endif
+                parse_square(std::integral_constant<int, 8>());
             {
                 constexpr int G = 1 << PAR_SQ;
 #pragma unroll
@@ -410,6 +452,11 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             const bool act = lane < nseq;
             const int opNext = __builtin_amdgcn_readlane(outEnd, nseq - 1);
             const int ipNext = ipW0 + __builtin_amdgcn_readlane((int)nxt, nseq - 1);
+            if (PAR_ADAPT && !fromList && nseq >= 16) {
+                // nodes per lane of the next batch: enough window for 64 sequences of this batch's average size
+                const int need = (ipNext - ip) * LZ4_WAVE;             // compressed bytes of 64 such sequences, times nseq
+                nodesPerLane = (need <= PAR_ADAPT6 * nseq) ? 6 : ((need <= 520 * nseq || !PAR_ADAPT10) ? 8 : 10);
+            }
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
             const bool ext = TOL && spos < 0;                       // source starts in the previous block: deferred
             const bool nearSrc = spos >= ringBase && !ext;
