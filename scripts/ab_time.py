@@ -37,7 +37,9 @@ for kind in sys.argv[1].split(","):
     out_line.append("%%s: dec %%.0f GB/s (U+C %%.0f) enc %%.0f GB/s ratio %%.3f ok=%%s" %% (kind, U / tds[2] / 1e6, (U + C) / tds[2] / 1e6, U / tc / 1e6, U / C, ok))
 print(" | ".join(out_line))
 ''' % (ROOT, ROOT)
-libs = [os.path.join(ROOT, "streamly-lz4_amd", "lib", "libmi355lz4.so")] + sorted(glob.glob(os.path.join(ROOT, "streamly-lz4_amd", "lib", "variants", "*.so")))
+main = os.path.join(ROOT, "streamly-lz4_amd", "lib", "libmi355lz4.so")
+# the working tree's build runs first AND last: the first process of a session on a fresh box measures 1-2 % low
+libs = [main] + sorted(glob.glob(os.path.join(ROOT, "streamly-lz4_amd", "lib", "variants", "*.so"))) + [main]
 for lib in libs:
     env = dict(os.environ, MI355LZ4_LIB=lib)
     r = subprocess.run([sys.executable, "-c", child, kinds, nb], env=env, capture_output=True, text=True)

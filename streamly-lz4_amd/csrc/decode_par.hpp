@@ -365,14 +365,18 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                     wave_fence();
                 }
             };
-#if PAR_ADAPT
+#ifdef PAR_FORCE_NL
+            parse_square(std::integral_constant<int, PAR_FORCE_NL>());     // experiments: one fixed form
+#elif PAR_ADAPT
             if (nodesPerLane == 6) parse_square(std::integral_constant<int, 6>());
 #if PAR_ADAPT10
             else if (nodesPerLane == 10) parse_square(std::integral_constant<int, 10>());
 #endif
             else
-#endif
                 parse_square(std::integral_constant<int, 8>());
+#else
+                parse_square(std::integral_constant<int, 8>());
+#endif
             {
                 constexpr int G = 1 << PAR_SQ;
 #pragma unroll
