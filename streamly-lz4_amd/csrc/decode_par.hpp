@@ -44,6 +44,11 @@ namespace lz4dev {
 #ifndef PAR_ADAPT
 #define PAR_ADAPT 1         // nodes per lane chosen per batch from the compressed bytes per sequence of the batch before: 6 or 8
 #endif
+#ifndef PAR_TAIL_ROUND
+#define PAR_TAIL_ROUND 2    // > 0: after this many dependency rounds the matches still waiting are copied one by one, in order, by the
+                            // whole wave.  Measured (lzsynth / text, GB/s): 0 = rounds only 958 / 627, 1: 889 / 585, 2: 992 / 634, 3: 961 / 614,
+                            // 4: 943 / 609; "as soon as fewer than 8 lanes are ready" instead of a fixed count: 984 / 602
+#endif
 #ifndef PAR_ADAPT6
 #define PAR_ADAPT6 416      // six nodes per lane while 64 sequences of the last batch's size need at most this many compressed bytes
 #endif
@@ -681,7 +686,40 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
             bool pending = act && nearSrc;                              // my match still has to be copied
             const uint32_t msA = nearSrc ? (uint32_t)(spos - ringBase) + A : 0u;
+            int roundNo = 0;
             while (~done) {
+#if PAR_TAIL_ROUND
+                if (!TOL && roundNo >= PAR_TAIL_ROUND) {
+                    // The matches that are still waiting after PAR_TAIL_ROUND rounds (dependency depth beyond it: a tenth of
+                    // the sequences, one to three lanes per further round) are copied ONE AFTER THE OTHER in sequence order by
+                    // the whole wave, a byte per lane: in that order every source is complete, so no round -- with its two
+                    // reads, six stores and class tests for a lane or two -- is needed for them.
+                    for (uint64_t sm = __ballot(pending); sm; sm &= sm - 1) {
+                        if (STATS) sc[PS_MATCH_ITERS]++;
+                        const int k = (int)__builtin_ctzll(sm);
+                        const uint32_t kd = (uint32_t)__builtin_amdgcn_readlane((int)mdA, k);
+                        const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)msA, k);
+                        const uint32_t koff = (uint32_t)__builtin_amdgcn_readlane((int)off16, k);
+                        const uint32_t kml = (uint32_t)__builtin_amdgcn_readlane((int)ml, k);
+                        if (koff >= kml) {
+                            if ((uint32_t)lane < kml) L.ring[kd + (uint32_t)lane] = L.ring[ks + (uint32_t)lane];
+                            for (uint32_t j = (uint32_t)lane + LZ4_WAVE; j < kml; j += LZ4_WAVE) L.ring[kd + j] = L.ring[ks + j];
+                        } else {
+                            const float rcp = 1.0f / (float)koff;
+                            for (uint32_t j = (uint32_t)lane; j < kml; j += LZ4_WAVE) {
+                                const uint32_t q = (uint32_t)((float)j * rcp);
+                                int rem = (int)j - (int)(q * koff);
+                                if (rem < 0) rem += (int)koff; else if (rem >= (int)koff) rem -= (int)koff;
+                                L.ring[kd + j] = L.ring[ks + (uint32_t)rem];
+                            }
+                        }
+                        wave_fence();
+                    }
+                    pending = false;
+                    break;
+                }
+                roundNo++;
+#endif
                 const bool ready = pending && ((need & ~done) == 0ull);
                 bool mine = ready;
                 if (TOL) {
