@@ -431,6 +431,9 @@ ArrayBatch decompressChunksBatch(const BlockConfig &cfg, const FrameConfig &conf
                         res.off[(size_t)nb] = pos;
                         return res;
                     }
+                    // A block the decoder rejected: the arrays are decoded a second time below, by the combinators, because
+                    // that is what raises the reference's error at the reference's block (the batch call only says that some
+                    // block failed).  The double decode is paid on the error path only.
                     res.release();
                 }
             }
