@@ -152,6 +152,26 @@ __device__ __forceinline__ void lds_mskor(uint32_t *w, uint32_t mask, uint32_t b
     asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"((uint32_t)(uintptr_t)w), "v"(mask), "v"(bits) : "memory");
 }
 
+// v_writelane_b32: lane k of v becomes the wave-uniform x.  (This clang has no builtin for it; the LLVM intrinsic is
+// reached by name, and the compiler then takes care of gfx9's rule that the lane select travels in M0 when the value
+// is an SGPR too.)
+extern "C" __device__ int enc_llvm_writelane(int x, int k, int v) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int enc_writelane(int v, int x, int k) { return enc_llvm_writelane(x, k, v); }
+
+// ballot of a predicate (HIP's __ballot takes an int: the predicate would travel through a register as 0 / 1 and a compare)
+__device__ __forceinline__ uint64_t enc_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+// minimum over each group of four lanes, in all four: two v_min_u32 with a quad_perm DPP operand.  (Written out: the
+// compiler keeps a copy and a v_mov_dpp per step otherwise.  The s_nop is the two wait states a DPP read of a
+// freshly written register needs; the hazard pass does not look into asm.)
+__device__ __forceinline__ uint32_t enc_quad_min(uint32_t g)
+{
+    uint32_t r;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(g));
+    return r;
+}
+
 // diagnostics (ENC_STATS builds only): cycles per phase of the dense-window path
 #ifdef ENC_STATS
 #define ENC_LAP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); est[i] += now_ - etm; etm = now_; } while (0)
@@ -298,11 +318,26 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
     // Sequence queue: selected sequences are parked one per lane (registers only) and written out
     // 64 at a time, so the emission code (:1022-1046, :1065-1135) runs with every lane busy instead of
-    // once per window for the handful of lanes that own a match.
-    int qPrev = 0, qStart = 0, qLen = 0, qOff = 0;     // literal start, match start, match length, offset
+    // once per window for the handful of lanes that own a match.  Fields: literal start, match start, match
+    // length, offset.  SMALLQ (positions below 64 Ki: independent blocks of up to 64 KiB): two fields to a register --
+    // q0 = literal start | match start << 16, q1 = match length | offset << 16 -- so that a window moves its
+    // sequences into the queue with two cross-lane operations instead of four.
+    constexpr bool SMALLQ = !DICT && !SEG && sizeof(TabT) == 2;
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     int qCnt = 0;                                      // uniform
+    uint64_t pendM0 = 0, pendM1 = 0;                   // dense windows: queue moves under way (commit_pending)
+    int pendR[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto commit_pending = [&]() {
+        if (__builtin_amdgcn_inverse_ballot_w64(pendM0)) { q0 = pendR[0][0]; q1 = pendR[0][1]; if (!SMALLQ) { q2 = pendR[0][2]; q3 = pendR[0][3]; } }
+        if (__builtin_amdgcn_inverse_ballot_w64(pendM1)) { q0 = pendR[1][0]; q1 = pendR[1][1]; if (!SMALLQ) { q2 = pendR[1][2]; q3 = pendR[1][3]; } }
+        pendM0 = 0; pendM1 = 0;
+    };
     auto flush_queue = [&]() {
+        commit_pending();
         if (qCnt == 0) return;
+        int qPrev, qStart, qLen, qOff;
+        if (SMALLQ) { qPrev = q0 & 0xffff; qStart = (int)((uint32_t)q0 >> 16); qLen = q1 & 0xffff; qOff = (int)((uint32_t)q1 >> 16); }
+        else { qPrev = q0; qStart = q1; qLen = q2; qOff = q3; }
         if (SEG) {
             // segment mode: the sequences go to the segment's list; a second kernel stitches the lists into the block
             if (lane < qCnt) seg->list[seg->count + (uint32_t)lane] = seg_pack(qStart + seg->base, qLen, qOff);
@@ -312,6 +347,17 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         }
         op = emit_sequences(src, op, qPrev, qStart, qLen, qOff, qCnt);
         qCnt = 0;
+    };
+    // one sequence whose fields are wave-uniform, into slot qCnt (the caller has made room)
+    auto park_uniform = [&](const int prev, const int start, const int len, const int off) {
+        if (SMALLQ) {
+            q0 = enc_writelane(q0, prev | (start << 16), qCnt);
+            q1 = enc_writelane(q1, len | (off << 16), qCnt);
+        } else {
+            q0 = enc_writelane(q0, prev, qCnt); q1 = enc_writelane(q1, start, qCnt);
+            q2 = enc_writelane(q2, len, qCnt); q3 = enc_writelane(q3, off, qCnt);
+        }
+        qCnt++;
     };
 
     if (blockLen == 0) {                // cbits/lz4.c:1263-1273: empty input -> single 0 token
@@ -366,79 +412,48 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
 #ifndef ENC_NO_PIPE
         // ===================================================================================================
-        // Dense window, one round trip (round 3).  Round 2's window (the code further down, still used for the
-        // last windows of a block) is a chain of dependent memory round trips -- bytes -> table -> candidate ->
-        // one to three extension steps per run head, in per-lane loops -- and a wave spent two thirds of its
-        // cycles waiting.  Here every run head is handed to a GROUP OF FOUR LANES that requests, in one go,
-        // 16 bytes per lane around the head's position and around its candidate: the 8 bytes before them
-        // (catch up, :1019) and the 56 after.  The tags make a candidate a real match nine times in ten, so
-        // there is no separate verification step: one round trip per window, every lane busy, and the lengths
-        // of up to 32 heads come out of two quad-DPP reductions.  A match that reaches the 56-byte horizon is
-        // extended by the whole wave, 1 KiB a step, and only if the greedy selection takes it.
-        //   A (probe)   hash the 64 positions, read buckets and tags, run heads, groups, requests
-        //   C (finish)  lengths per group, every lane learns its run's head (DPP max-scan), greedy selection
-        //               (scalar, as below), the probed positions outside the selected matches go into the table
-        //               (:998, the reference's policy), sequences are queued
-        // The next window starts at the end of the last selected match; its bytes are requested as soon as
-        // the selection knows that position.
-        // Measured on the way (MI355X, lzsynth / text, 16 384 blocks): two windows in flight per wave (window
-        // w+1 probed before window w is finished, on a fixed 64-position grid, every probed position written
-        // into the table at once and positions that turn out to lie inside a selected match taking their
-        // insertion back a window later; oracle/sim_encode2.c has the policy: ratio 2.915 / 1.841 against
-        // 2.895 / 1.838) 132 / 112 GB/s; one window at a time, this code, 150 / 109 GB/s: the fixed grid
-        // costs 17 % more windows (1022 against 875 per block) and a window costs its ~200 vector
-        // instructions whatever is in flight -- at 16 waves per CU the vector ALU is 80 % busy either way.
+        // Dense window, one round trip.  The window code further down (still used for the first and the last
+        // windows of a block) is a chain of dependent memory round trips -- bytes -> table -> candidate -> one to
+        // three extension steps per run head, in per-lane loops.  Here every run head is handed to a GROUP OF FOUR
+        // LANES that requests, in one go, 16 bytes per lane around the head's position and around its candidate:
+        // the 8 bytes before them (catch up, :1019) and the 56 after.  The tags make a candidate a real match nine
+        // times in ten, so there is no separate verification step: one round trip per window, every lane busy.
+        //   probe    hash the 64 positions, read buckets and tags, run heads, groups, requests
+        //   lengths  first difference per group (one chain of v_ffbl / v_min and two quad-DPP steps), every lane
+        //            learns its run's head with a DPP max-scan
+        //   select   greedy, left to right: a scalar loop that only reads the END of each match it takes
+        //   finish   what each selected lane needs -- the end of the selected match before it -- comes from one more
+        //            max-scan; catch up, the sequence's fields and their move into the queue are vector code whose
+        //            cost does not depend on the number of matches
+        // Round 5 rewrote this section for instruction count (the kernel is bound by vector issue: round 4 measured
+        // 228 vector instructions per window of 75 input bytes): group lengths 44 -> 28 instructions, no per-match
+        // vector work in the selection loop (it was 8 per match), lane predicates taken from scalar masks
+        // (inverse ballot) instead of 64-bit shifts per lane, the queue's fields packed two to a register for
+        // blocks of up to 64 KiB (two cross-lane moves per window instead of four), no address selects for
+        // unused groups (they read bytes that are there anyway).
         // ===================================================================================================
         const LZ4_GLOBAL uint8_t *gsrc = as_global(src);
-        auto load16 = [&](int off) -> dev_v4 { return *(const LZ4_GLOBAL dev_v4u *)(gsrc + (uint32_t)off); };
-        auto quad = [](uint32_t v, const int ctrl) -> uint32_t {      // quad_perm broadcast
-            return ctrl == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true)
-                 : ctrl == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true)
-                 : ctrl == 2 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xaa, 0xf, 0xf, true)
-                             : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xff, 0xf, 0xf, true);
-        };
-        const bool pipeFits = n <= (1 << 25);          // a group's head travels as a 25-bit position
-        // the last request of a window ends 136 bytes behind its first position
-        auto pipe_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 + 136 <= n && pipeFits; };
-        const uint32_t lanePay = 0x80000000u | ((uint32_t)lane << 25);   // a head's message to its group: valid | lane | candidate
-        const int j16m8 = (lane & 3) * 16 - 8;
+        auto load16 = [&](uint32_t off) -> dev_v4 { return *(const LZ4_GLOBAL dev_v4u *)(gsrc + off); };
+        const bool pipeFits = n < (1 << 24);           // a group's candidate travels in 25 bits, an end in 24
+        // lane constants of the groups: lane j of a group holds bytes [16 j - 8, 16 j + 8) relative to the head
+        const uint32_t j4 = (uint32_t)lane & 3u;
+        const uint32_t gc0 = j4 << 7, gc1 = gc0 | 32u, gc2 = gc0 | 64u, gc3 = gc0 | 96u;    // bit offsets of a lane's four words
+        const uint32_t fwdMask = j4 ? 0xffffffffu : 0u;       // a group's lane 0: its first 8 bytes lie BEFORE the head
+        const uint32_t j16 = j4 << 4;
+        const uint32_t lanePay = (uint32_t)lane << 25;        // a head's message to its group: lane | candidate - 8
 
-        // match length of a group's head from the 4 x 16 bytes of the group (meaningful in the group's lane 0):
-        // forward length (0..56) | equal bytes before the head (0..8) << 8 | four equal bytes << 12 | horizon reached << 13
-        auto groupLen = [&](const dev_v4 &a, const dev_v4 &b) -> uint32_t {
+        // First difference of a group's 64 + 64 bytes, in every lane of the group:
+        //   bits 0..7  t = 8 + equal bytes from the head on (8..64; 64 = the horizon of 56 bytes was reached)
+        //   bits 8..11 equal bytes just before the head (0..8), meaningful in the group's lane 0 only
+        // v_ffbl_b32 gives 0..31 or ~0: "or"-ing the word's bit offset in keeps ~0 for equal words, so the minimum over
+        // the group is the first differing bit of its 512 (or ~0).
+        auto group_len = [&](const dev_v4 &a, const dev_v4 &b) -> uint32_t {
             const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-            const uint32_t l0 = ffbl32(x0), l1 = ffbl32(x1) | 32u, l2 = ffbl32(x2), l3 = ffbl32(x3) | 32u;
-            const uint32_t lo8 = min(min(l0, l1) >> 3, 8u);                        // equal bytes from byte 0 on (0..8)
-            const uint32_t hi8 = min(min(l2, l3) >> 3, 8u);                        // equal bytes from byte 8 on (0..8)
-            const uint32_t f16 = (lo8 == 8u) ? 8u + hi8 : lo8;
-            // a group's lane 0: bytes 0..7 lie before the head (counted backwards from byte 7), bytes 8..15 are its first eight
+            uint32_t g = min(min(ffbl32(x0 & fwdMask) | gc0, ffbl32(x1 & fwdMask) | gc1), min(ffbl32(x2) | gc2, ffbl32(x3) | gc3));
+            g = enc_quad_min(g);
+            const uint32_t t = min(g >> 3, 64u);
             const uint32_t back = min(min(ffbh32(x1), ffbh32(x0) | 32u) >> 3, 8u);
-            const bool first = (lane & 3) == 0;
-            const uint32_t f = first ? hi8 : f16, full = first ? 8u : 16u;
-            const uint32_t f1 = quad(f, 1), f2 = quad(f, 2), f3 = quad(f, 3);
-            uint32_t total = f;
-            total += (f == full) ? f1 : 0u;
-            total += (f == full && f1 == 16u) ? f2 : 0u;
-            total += (f == full && f1 == 16u && f2 == 16u) ? f3 : 0u;
-            return total | (back << 8) | ((uint32_t)(f >= (uint32_t)LZ4_MINMATCH) << 12) | ((uint32_t)(total == 56u) << 13);
-        };
-
-        // heads beyond the 32nd of a window (two rounds of 16 groups are requested up front): one more round of groups at
-        // a time, requested and waited for here.  Generated text has 14-17 heads per window; source code 25-27, and
-        // leaving the heads past the 32nd without a match cost 2 % of its ratio (oracle/sim_encode2.c, headcap32).
-        auto more_rounds = [&](const int p0w, const uint64_t headm, const bool head, const uint32_t rank4, const uint32_t cand, uint32_t r) -> uint32_t {
-            const int nH = (int)__builtin_popcountll(headm);
-            for (int rr = 2; rr * 16 < nH; rr++) {
-                const int dest = (head && (int)(rank4 >> 8) == rr) ? (int)(rank4 & 255u) : 4;
-                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | cand)), 0);
-                const bool gv = (int)gi < 0;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                const dev_v4 a = load16(gv ? p0w + hl + j16m8 : p0w);
-                const dev_v4 b = load16(gv ? c + j16m8 : p0w);
-                const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a, b));
-                if ((int)(rank4 >> 8) == rr) r = r2;
-            }
-            return r;
+            return t | (back << 8);
         };
 
         // a match that reached the horizon: the whole wave counts on, 16 bytes a lane
@@ -450,14 +465,14 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 uint32_t d = 0;
                 bool full = false;
                 if (off + 16 <= maxExtra) {
-                    const dev_v4 a = load16(pe + off), b = load16(ce + off);
+                    const dev_v4 a = load16((uint32_t)(pe + off)), b = load16((uint32_t)(ce + off));
                     d = common16x(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
                     full = d == 16u;
                 } else if (off < maxExtra) {
                     const uint32_t r = (uint32_t)(maxExtra - off);
                     while (d < r && gsrc[pe + off + (int)d] == gsrc[ce + off + (int)d]) d++;
                 }
-                const uint64_t ne = ~__ballot(full);
+                const uint64_t ne = ~enc_ballot(full);
                 if (ne == 0ull) { total += 16 * LZ4_WAVE; continue; }
                 const int first = (int)__builtin_ctzll(ne);
                 total += 16 * first + __builtin_amdgcn_readlane((int)d, first);
@@ -466,191 +481,213 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             return total;
         };
 
-        // The tail of a window -- catch up and parking the selected sequences in the queue, which touch neither the
-        // table nor the anchor -- is put off until the NEXT window has issued its requests: it then runs while those
-        // are in flight instead of in front of them (the wave's chain of dependent waits per window is what its rate
-        // follows: 16 waves per CU, each waiting two thirds of the time).
-        struct Tail {                                        // a window's pending tail
-            uint64_t selm = 0;                               // selected lanes (0 = nothing pending)
-            int p0 = 0, prevEnd = 0, ml = 0, back = 0;       // its window, and per lane: literal start, match length, equal bytes before
-            uint32_t cand = 0;
-            int r0 = 0, r1 = 0, r2 = 0, r3 = 0, k = 0;       // the cross-lane moves under way
-        } tl[2];                                             // (two: the pair form below finishes two windows at a time)
-        // ... in two halves, so that its four cross-lane moves travel with the next window's table reads (one LDS round
-        // trip for both) and are only looked at once that window's requests are out.  Without a pending tail (selm = 0)
-        // both halves do nothing: no branch, so that the compiler can interleave them with the window's own code.
-        auto tail_issue1 = [&](Tail &t, const int qBase) {
-            const uint64_t selm = t.selm;
-            const bool sel = (selm >> lane) & 1ull;
-            const int myPos = t.p0 + lane;
-            // ---- catch up (:1019), bounded by the previous match: the bytes between my run's head and me
-            // are known equal, the head's group measured up to 8 more before the head ----
-            int mstart = myPos, mcand = (int)t.cand;
-            if (sel) {
-                const int room = min(mstart - t.prevEnd, mcand);
-                const int back = min(room, t.back);
-                mstart -= back; mcand -= back;
-            }
-            // ---- park the selected sequences in the queue (stable compaction, one ds_permute per field) ----
-            t.k = (int)__builtin_popcountll(selm);
-            const int rk = (int)enc_mbcnt(selm);
-            const int dest = (sel ? qBase + rk : qBase + t.k + (lane - rk)) & 63;
-            t.r0 = __builtin_amdgcn_ds_permute(dest << 2, t.prevEnd);
-            t.r1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
-            t.r2 = __builtin_amdgcn_ds_permute(dest << 2, myPos + t.ml - mstart);
-            t.r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
-            t.selm = 0;
-        };
-        auto tail_commit1 = [&](Tail &t) {
-            if (lane >= qCnt && lane < qCnt + t.k) { qPrev = t.r0; qStart = t.r1; qLen = t.r2; qOff = t.r3; }
-            qCnt += t.k;
-            t.k = 0;
-        };
-        bool tailSplit = false;                              // the two pending tails did not fit the queue together
-        auto tail_issue = [&]() {
-            if constexpr (!PAIR) {
-                if (qCnt + (int)__builtin_popcountll(tl[0].selm) > LZ4_WAVE) flush_queue();
-                tail_issue1(tl[0], qCnt);
-                return;
-            }
-            const int k0 = (int)__builtin_popcountll(tl[0].selm), k1 = PAIR ? (int)__builtin_popcountll(tl[1].selm) : 0;
-            if (qCnt + k0 + k1 > LZ4_WAVE) {
-                // (rare: once per 64 sequences) one after the other, with the queue written out in between
-                if (qCnt + k0 > LZ4_WAVE) flush_queue();
-                tail_issue1(tl[0], qCnt); tail_commit1(tl[0]);
-                if constexpr (PAIR) {
-                    if (qCnt + k1 > LZ4_WAVE) flush_queue();
-                    tail_issue1(tl[1], qCnt); tail_commit1(tl[1]);
-                }
-                tailSplit = true;
-                return;
-            }
-            tailSplit = false;
-            tail_issue1(tl[0], qCnt);
-            if constexpr (PAIR) tail_issue1(tl[1], qCnt + k0);
-        };
-        auto tail_commit = [&]() {
-            if constexpr (!PAIR) { tail_commit1(tl[0]); return; }
-            if (tailSplit) { tailSplit = false; return; }
-            tail_commit1(tl[0]);
-            if constexpr (PAIR) tail_commit1(tl[1]);
-        };
-        auto window_tail = [&]() { tail_issue(); tail_commit(); };
-
-        // one window: positions [p0, p0 + 64), p0 >= anchor; returns where the next one starts
-        auto group_window = [&](const int p0) -> int {
-            // ---- A: probe ----
-            const int myPos = p0 + lane;
-            if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)myPos);
-            const uint32_t hx = hash5x(pfV8);
-            const uint32_t h = hx >> 4, tg = hx & 15u;
-            const uint32_t tsh = (hx >> 2) & 28u;                 // (h & 7) * 4
-            uint32_t *tagw = &tags[hx >> 7];                      // h >> 3
-            const uint32_t oldp = table[h], tagWord = *tagw;
-            tail_issue();                                      // the window before this one: its cross-lane moves ride along
-            const uint32_t oldt = (tagWord >> tsh) & 15u;
-            uint32_t cand = 0;
-            const bool candOk = tab_candidate<TabT, DICT>((TabT)oldp, myPos, cand) && oldt == tg && cand >= 8u;
-            // run heads: a candidate that continues its left neighbour's belongs to the same copied region
-            // (a lane without a candidate sends ~0, and ~0 + 1 = 0 is no candidate: they start at 8)
-            const uint32_t cv = candOk ? cand : 0xffffffffu;
-            const uint32_t prevCand = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool head = candOk && cand != prevCand + 1u;
-            const uint64_t headm = __ballot(head);
-            const bool twoRounds = (headm >> 16) != 0ull && __builtin_popcountll(headm) > 16;
-            const uint32_t rank4 = enc_mbcnt(headm) << 4;         // byte address of lane 4 * rank
-            const uint32_t payload = lanePay | cand;              // positions stay below 2^25 (blocks <= 4 MiB + dictionary)
+        // One window's state.  Lane l stands for position p0w + l; idx = l (+ 64 in the second window of a pair).
+        struct LW {
+            uint32_t hx, oldp, tagWord, tmask, tbits;   // probe: hash bits, the bucket's entry and tag word as found, this position's tag in place
+            uint32_t c8, cv;                            // candidate - 8; the same or ~1 without a candidate
+            bool candOk, head, twoRounds;
+            uint64_t headm;
+            uint32_t rank4, gi0;
             dev_v4 a0, b0, a1, b1;
-            // round 0: heads 0..15, one per group of four lanes (lane 1 takes what the others send)
-            {
-                const int dest = (head && rank4 < 256u) ? (int)rank4 : 4;
-                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)payload), 0);
-                const bool gv = (int)gi < 0;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                a0 = load16(gv ? p0 + hl + j16m8 : p0);
-                b0 = load16(gv ? c + j16m8 : p0);
+            uint32_t hv;                                // (head idx + 1) << 16 | back << 8 | t + head idx, of the run this lane belongs to
+            uint32_t m0;                                // hit lanes: match length from this lane on (0..56; 63 once extended)
+            int endv;                                   // hit lanes: end of that match
+            uint64_t hitm, capm;
+        };
+        auto lw_probe = [&](LW &W, const uint32_t pos, const uint64_t v8, const bool insertNow) {
+            const uint32_t hx = hash5x(v8);
+            const uint32_t tsh = (hx >> 2) & 28u;                  // (h & 7) * 4
+            W.hx = hx;
+            W.tmask = 15u << tsh;
+            W.tbits = (hx & 15u) << tsh;
+            W.oldp = table[hx >> 4];
+            W.tagWord = tags[hx >> 7];
+            if (insertNow) {                                       // every position, at once: the window behind this one probes next
+                table[hx >> 4] = (TabT)pos;
+                lds_mskor(&tags[hx >> 7], W.tmask, W.tbits);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            // round 1: heads 16..31 (one window in four has them)
-            if (twoRounds) {
-                const int dest = (head && (rank4 >> 8) == 1u) ? (int)(rank4 & 255u) : 4;
-                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)payload), 0);
-                const bool gv = (int)gi < 0;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                a1 = load16(gv ? p0 + hl + j16m8 : p0);
-                b1 = load16(gv ? c + j16m8 : p0);
+        };
+        auto lw_heads = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t cvBefore) {
+            const bool tagOk = (W.tagWord & W.tmask) == W.tbits;
+            uint32_t c8;
+            bool ok;
+            if (DICT || sizeof(TabT) != 2) {
+                uint32_t cand = 0;
+                ok = tab_candidate<TabT, DICT>((TabT)W.oldp, (int)pos, cand) && cand >= 8u;
+                c8 = cand - 8u;
+            } else {
+                c8 = W.oldp - 8u;                                  // positions stay below 64 Ki: the entry IS the position,
+                ok = c8 < pos8;                                    // and 8 <= cand < pos in one unsigned compare (:1003-1006)
             }
-            ENC_LAP(0);
-            tail_commit();                                     // (the requests are out: the moves' results are looked at now)
-            // ---- C: finish ----
-            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a0, b0));
-            if (twoRounds) {
-                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank4 & 255u), (int)groupLen(a1, b1));
-                if (rank4 >= 256u) r = r1;
+            W.candOk = tagOk && ok;
+            W.c8 = c8;
+            // run heads: a candidate that continues its left neighbour's belongs to the same copied region
+            W.cv = W.candOk ? c8 : 0xfffffffeu;
+            const uint32_t prevC = (uint32_t)__builtin_amdgcn_update_dpp((int)cvBefore, (int)W.cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            W.head = W.candOk && c8 != prevC + 1u;
+            W.headm = enc_ballot(W.head);
+            W.twoRounds = __builtin_popcountll(W.headm) > 16;
+            W.rank4 = enc_mbcnt(W.headm) << 4;                     // byte address of lane 4 * rank
+            // heads 0..15, one per group of four lanes (lane 1 takes what the others send)
+            const int dest = (W.head && W.rank4 < 256u) ? (int)W.rank4 : 4;
+            W.gi0 = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | c8));
+        };
+        // a group's requests.  A group without a head decodes lane 0, candidate 8: bytes that are there (p0w >= 8)
+        auto lw_fetch = [&](const uint32_t giRaw, const int p0w, dev_v4 &a, dev_v4 &b) {
+            const uint32_t gi = (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0x00 /* quad_perm 0,0,0,0 */, 0xf, 0xf, true);
+            a = load16((uint32_t)(p0w - 8) + (gi >> 25) + j16);
+            b = load16((gi & 0x1ffffffu) + j16);
+        };
+        auto lw_loads = [&](LW &W, const int p0w) {
+            lw_fetch(W.gi0, p0w, W.a0, W.b0);
+            if (W.twoRounds) {                                     // heads 16..31 (one window in four has them)
+                const int dest = (W.head && (W.rank4 >> 8) == 1u) ? (int)(W.rank4 & 255u) : 4;
+                lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, W.a1, W.b1);
+            }
+        };
+        // heads beyond the 32nd of a window: one more round of groups at a time, requested and waited for here.
+        // Generated text has 14-17 heads per window; source code 25-27, and leaving the heads past the 32nd without a
+        // match cost 2 % of its ratio (oracle/sim_encode2.c, headcap32).
+        auto more_rounds = [&](const LW &W, const int p0w, uint32_t r) -> uint32_t {
+            const int nH = (int)__builtin_popcountll(W.headm);
+            for (int rr = 2; rr * 16 < nH; rr++) {
+                const int dest = (W.head && (int)(W.rank4 >> 8) == rr) ? (int)(W.rank4 & 255u) : 4;
+                dev_v4 a, b;
+                lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, a, b);
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(a, b));
+                if ((int)(W.rank4 >> 8) == rr) r = r2;
+            }
+            return r;
+        };
+        // lengths: headConst = (idx + 1) << 16 | idx, idx8 = idx + 8; hvBefore = the scan value of the last lane of the
+        // window before (its run may go on into this one)
+        auto lw_lengths = [&](LW &W, const int p0w, const uint32_t pos, const uint32_t headConst, const uint32_t idx8, const uint32_t hvBefore) {
+            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a0, W.b0));
+            if (W.twoRounds) {
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a1, W.b1));
+                if (W.rank4 >= 256u) r = r1;
             }
 #ifdef ENC_STATS
-            est[7] += (unsigned)__builtin_popcountll(headm);
+            est[7] += (unsigned)__builtin_popcountll(W.headm);
 #endif
-            // every lane learns its run's head (lane and result) with a max-scan: head lanes put (lane + 1) << 16 | result
-            // in, the others 0, and the largest value at or below a lane belongs to the nearest head below it
-#ifndef ENC_EXP_NOMORE
-            if (headm >> 32 && __builtin_popcountll(headm) > 32) r = more_rounds(p0, headm, head, rank4, cand, r);
-#endif
-            const uint32_t hv = enc_scan_max(head ? (((uint32_t)lane + 1u) << 16) | r : 0u);
-            const int delta = lane + 1 - (int)(hv >> 16);                 // lanes between my run's head and me
-            const int m0 = (int)(hv & 0xffu) - delta;
-            const bool hit = candOk && ((hv >> 12) & 1u) && m0 >= LZ4_MINMATCH;
-            uint32_t myMl = hit ? (uint32_t)m0 : 0u;
-            ENC_LAP(1);
-            // ---- greedy left-to-right selection ----
-            const uint64_t hitm = __ballot(hit);
-            if (!hitm) {
+            if (__builtin_popcountll(W.headm) > 32) r = more_rounds(W, p0w, r);
+            // every lane learns its run's head with a max-scan: head lanes put their index above their result, the others 0,
+            // and the largest value at or below a lane belongs to the nearest head below it.  The low byte is t + head idx,
+            // so that a lane's own length is one subtraction: (t - 8) - (idx - head idx).
+            W.hv = max(enc_scan_max(W.head ? r + headConst : 0u), hvBefore);
+            const int m0 = (int)(W.hv & 0xffu) - (int)idx8;
+            const bool hit = W.candOk && m0 >= LZ4_MINMATCH;
+            W.m0 = (uint32_t)m0;
+            W.endv = (int)pos + m0;
+            W.hitm = enc_ballot(hit);
+            // ... and whether its run reached the horizon: t = 64
+            W.capm = enc_ballot(hit && (W.hv & 0xffu) - (W.hv >> 16) == 63u);
+        };
+        // greedy selection in this window, continuing from pEnd (the end of the last selected match so far): scalar, one
+        // v_readlane per match taken
+        auto lw_select = [&](LW &W, const int p0w, int &pEnd) -> uint64_t {
+            uint64_t hm = W.hitm;
+            const int lowcut = pEnd - p0w;
+            if (lowcut > 0) hm = (lowcut >= LZ4_WAVE) ? 0ull : (hm & (~0ull << lowcut));
+            uint64_t selm = 0;
+            while (hm) {
+                const int k = (int)__builtin_ctzll(hm);
+                int endk = __builtin_amdgcn_readlane(W.endv, k);
+                if ((W.capm >> k) & 1ull) {
+                    const int ce = __builtin_amdgcn_readlane((int)W.c8, k) + 8 + (endk - (p0w + k));
+                    endk += extend_long(endk, ce);
+                    W.endv = enc_writelane(W.endv, endk, k);
+                    W.m0 = (uint32_t)enc_writelane((int)W.m0, 63, k);        // (any length from ENC_END2_MINLEN up: an inline constant)
+                }
+                selm |= 1ull << k;
+                pEnd = endk;
+                const int sh = endk - p0w;
+                hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
+            }
+            return selm;
+        };
+        // The selected lanes' sequences.  P = end of the selected match before me (an exclusive max-scan over the selected
+        // lanes' ends, the match's clipped length riding in the low byte); covered = my position lies strictly inside a
+        // selected match and is not the one position (end - 2 of a long match, :1146) that stays registered.  The fields go
+        // to queue slots qCnt.. with one ds_permute per register; their results are looked at by commit_pending.
+        auto lw_finish = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t idx1, const uint64_t selm, const int pStart, const int slot) -> bool {
+            const bool sel = __builtin_amdgcn_inverse_ballot_w64(selm);
+            const uint32_t e = sel ? ((uint32_t)W.endv << 8) | W.m0 : 0u;
+            uint32_t sc = enc_scan_max((uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+            sc = max(sc, (uint32_t)pStart << 8);
+            const uint32_t P = sc >> 8;
+            const bool covered = pos < P && !((sc & 0xffu) >= (uint32_t)ENC_END2_MINLEN && pos + 2u == P);
+            // catch up (:1019), bounded by the previous match: the bytes between my run's head and me are known equal, the
+            // head's group measured up to 8 more before the head
+            const uint32_t backAvail = (idx1 - (W.hv >> 16)) + ((W.hv >> 8) & 15u);
+            const uint32_t back = min(min(backAvail, pos - P), W.c8);
+            const uint32_t start = pos - back, mlen = (uint32_t)W.endv - start, off = pos8 - W.c8;
+            const int k = (int)__builtin_popcountll(selm);
+            const int trash = ((qCnt + 40) & 63) << 2;              // a slot outside [qCnt, qCnt + k): k <= 17
+            const int dest = sel ? (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(selm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)selm, (uint32_t)qCnt)) << 2) : trash;
+            if (SMALLQ) {
+                pendR[slot][0] = __builtin_amdgcn_ds_permute(dest, (int)(P | (start << 16)));
+                pendR[slot][1] = __builtin_amdgcn_ds_permute(dest, (int)(mlen | (off << 16)));
+            } else {
+                pendR[slot][0] = __builtin_amdgcn_ds_permute(dest, (int)P);
+                pendR[slot][1] = __builtin_amdgcn_ds_permute(dest, (int)start);
+                pendR[slot][2] = __builtin_amdgcn_ds_permute(dest, (int)mlen);
+                pendR[slot][3] = __builtin_amdgcn_ds_permute(dest, (int)off);
+            }
+            (slot ? pendM1 : pendM0) = k ? (((1ull << k) - 1ull) << qCnt) : 0ull;
+            qCnt += k;
+            return covered;
+        };
+        // this position into its bucket / the bucket's entry as found put back if it still holds this position
+        auto lw_insert = [&](const LW &W, const uint32_t pos) {
+            table[W.hx >> 4] = (TabT)pos;
+            lds_mskor(&tags[W.hx >> 7], W.tmask, W.tbits);
+        };
+        auto lw_takeback = [&](const LW &W, const uint32_t pos) {
+            if (table[W.hx >> 4] == (TabT)pos) {
+                table[W.hx >> 4] = (TabT)W.oldp;
+                lds_mskor(&tags[W.hx >> 7], W.tmask, W.tagWord & W.tmask);
+            }
+        };
+        const uint32_t hc0 = (((uint32_t)lane + 1u) << 16) | (uint32_t)lane, hc1 = hc0 + ((64u << 16) | 64u);
+
+        // ---- one window per step: positions [p0, p0 + 64), p0 >= max(anchor, 8); returns where the next one starts.
+        // The probed positions outside the selected matches go into the table afterwards (:998, the reference's policy).
+        // the last request of a window ends 136 bytes behind its first position
+        auto pipe_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 >= 8 && p0 + 136 <= n && pipeFits; };
+        auto group_window = [&](const int p0) -> int {
+            const uint32_t pos = (uint32_t)(p0 + lane), pos8 = pos - 8u;
+            if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos);
+            LW W;
+            lw_probe(W, pos, pfV8, false);
+            lw_heads(W, pos, pos8, 0xfffffffeu);
+            lw_loads(W, p0);
+            ENC_LAP(0);
+            commit_pending();                                  // (the requests are out: the last window's moves are looked at now)
+            lw_lengths(W, p0, pos, hc0, (uint32_t)lane + 8u, 0u);
+            if (!W.hitm) {
                 // nothing here: every position is registered, the miss counter widens the stride (:957-967)
-                table[h] = (TabT)myPos;
-                lds_mskor(tagw, 15u << tsh, tg << tsh);
+                lw_insert(W, pos);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 missAcc += LZ4_WAVE;
                 pfPos = -1;
                 return p0 + LZ4_WAVE;
             }
-            const uint64_t capm = __ballot(hit && ((hv >> 13) & 1u));
-            uint64_t selm = 0;
             int pEnd = anchor;
-            int prevEnd = anchor;              // end of the selected match before me (selected lanes: my literal start)
-            bool longBefore = false;           // ... and that match is a long one
-            for (uint64_t hm = hitm; hm;) {
-                const int k = (int)__builtin_ctzll(hm);
-                int len = __builtin_amdgcn_readlane((int)myMl, k);
-                if ((capm >> k) & 1ull) {
-                    len += extend_long(p0 + k + len, __builtin_amdgcn_readlane((int)cand, k) + len);
-                    if (lane == k) myMl = (uint32_t)len;
-                }
-                const int endk = p0 + k + len;
-                selm |= 1ull << k;
-                pEnd = endk;
-                if (lane > k) { prevEnd = endk; longBefore = len >= ENC_END2_MINLEN; }
-                const int sh = endk - p0;
-                hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
-            }
-            const bool sel = (selm >> lane) & 1ull;
+            const uint64_t selm = lw_select(W, p0, pEnd);
+            ENC_LAP(1);
             // the next window starts at the end of the last match, or where this one ends: its bytes are requested now
             const int nextP = max(p0 + LZ4_WAVE, pEnd);
             pfPos = nextP;
             if (nextP + 72 <= n) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
             else pfPos = -1;
             ENC_LAP(2);
-            // ---- table: the probed positions outside the selected matches (:998) ----
-            // (... and, like the reference behind every match (:1146), the position two bytes in front of the end of a
-            // LONG match: behind every match it costs text 1.7 % of its ratio, behind matches of 16 bytes and more it
-            // costs nothing there and buys lzsynth 0.13 %)
-            if (sel || myPos >= prevEnd || (longBefore && myPos == prevEnd - 2)) {
-                table[h] = (TabT)myPos;
-                lds_mskor(tagw, 15u << tsh, tg << tsh);
-            }
+            if (qCnt + (int)__builtin_popcountll(selm) > LZ4_WAVE) flush_queue();
+            const bool covered = lw_finish(W, pos, pos8, (uint32_t)lane + 1u, selm, anchor, 0);
+            if (!covered) lw_insert(W, pos);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
-            // ---- catch up and the queue: put off (window_tail) ----
-            tl[0].selm = selm; tl[0].p0 = p0; tl[0].prevEnd = prevEnd; tl[0].ml = (int)myMl; tl[0].cand = cand;
-            tl[0].back = delta + (int)((hv >> 8) & 15u);
             anchor = pEnd;
             missAcc = miss0;
 #ifdef ENC_STATS
@@ -661,157 +698,40 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 
         // ===================================================================================================
         // Two windows per step (positions [p0, p0 + 128)).  A window is a chain of dependent waits -- table, groups,
-        // requests, lengths, selection -- and the chip has room for 16 such chains per CU (the table's LDS); the rate
-        // follows the number of chains, not the instructions.  Here one chain carries two windows, step by step side by
-        // side, so that each wait is paid once for both.  What the second window needs from the first is the table:
-        // every position of a window is written into its bucket when it is probed (the bucket's previous entry kept in
-        // a register), and positions that end up strictly inside a selected match take that back, last window first,
-        // before the next pair starts -- between pairs the table is the reference's (:998), within a pair the second
-        // window also sees the first one's covered positions (oracle/sim_encode2.c: the ratio goes UP, 2.895 -> 2.91).
+        // requests, lengths, selection -- and the chip has room for 16 such chains per CU (the table's LDS).  Here one
+        // chain carries two windows, step by step side by side, so that each wait is paid once for both.  What the second
+        // window needs from the first is the table: every position of a window is written into its bucket when it is
+        // probed (the bucket's previous entry kept in a register), and positions that end up strictly inside a selected
+        // match take that back, last window first, before the next pair starts -- between pairs the table is the
+        // reference's (:998), within a pair the second window also sees the first one's covered positions
+        // (oracle/sim_encode2.c).  The template parameter PAIR picks the form: blocks above 64 KiB, whose positions are
+        // modular, and segments run one window per step.
         // ===================================================================================================
-        struct PW {
-            uint32_t hx, oldp, tagWord, cand, cv;
-            bool candOk, head, twoRounds;
-            uint64_t headm, selm;
-            uint32_t rank4, gi0, hv, myMl;
-            int prevEnd, delta;
-            bool keep2;                      // the selected match before me is a long one: its end - 2 stays registered (:1146)
-            dev_v4 a0, b0, a1, b1;
-        };
         uint64_t pfV8b = 0;                                  // the second window's bytes (window at pfPos + 64)
         int pfPosB = -2;                                     // ... valid when pfPosB == pfPos (only this form requests them)
-        // (What it costs: the second window meets the first one's positions in the table before the covered ones are
-        // taken back -- lzsynth 2.891 -> 2.888, source text -0.5 % in the simulation -- which the registration behind
-        // long matches below more than gives back on lzsynth.  The template parameter PAIR picks the form: blocks above 64 KiB, whose positions are modular, and segments run one
-        // window per step.)
-        auto pair_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 + 200 <= n && pipeFits; };
-        auto pw_probe = [&](PW &W, const int p0w, const uint64_t v8) {
-            const uint32_t hx = hash5x(v8);
-            const uint32_t h = hx >> 4, tg = hx & 15u, tsh = (hx >> 2) & 28u;
-            uint32_t *tagw = &tags[hx >> 7];
-            W.hx = hx;
-            W.oldp = table[h];
-            W.tagWord = *tagw;
-            table[h] = (TabT)(p0w + lane);                     // every position, at once: the window behind this one probes next
-            lds_mskor(tagw, 15u << tsh, tg << tsh);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        };
-        auto pw_heads = [&](PW &W, const int p0w, const uint32_t cvBefore) {
-            const uint32_t tg = W.hx & 15u, tsh = (W.hx >> 2) & 28u;
-            const uint32_t oldt = (W.tagWord >> tsh) & 15u;
-            uint32_t cand = 0;
-            W.candOk = tab_candidate<TabT, DICT>((TabT)W.oldp, p0w + lane, cand) && oldt == tg && cand >= 8u;
-            W.cand = cand;
-            W.cv = W.candOk ? cand : 0xffffffffu;
-            // (lane 0 continues the run of the last lane of the window before it)
-            const uint32_t prevCand = (uint32_t)__builtin_amdgcn_update_dpp((int)cvBefore, (int)W.cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            W.head = W.candOk && cand != prevCand + 1u;
-            W.headm = __ballot(W.head);
-            W.twoRounds = (W.headm >> 16) != 0ull && __builtin_popcountll(W.headm) > 16;
-            W.rank4 = enc_mbcnt(W.headm) << 4;
-            const int dest = (W.head && W.rank4 < 256u) ? (int)W.rank4 : 4;
-            W.gi0 = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | cand));
-        };
-        auto pw_loads = [&](PW &W, const int p0w) {
-            {
-                const uint32_t gi = quad(W.gi0, 0);
-                const bool gv = (int)gi < 0;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                W.a0 = load16(gv ? p0w + hl + j16m8 : p0w);
-                W.b0 = load16(gv ? c + j16m8 : p0w);
-            }
-            if (W.twoRounds) {
-                const int dest = (W.head && (W.rank4 >> 8) == 1u) ? (int)(W.rank4 & 255u) : 4;
-                const uint32_t gi = quad((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.cand)), 0);
-                const bool gv = (int)gi < 0;
-                const int c = (int)(gi & 0x1ffffffu), hl = (int)((gi >> 25) & 63u);
-                W.a1 = load16(gv ? p0w + hl + j16m8 : p0w);
-                W.b1 = load16(gv ? c + j16m8 : p0w);
-            }
-        };
-        // lengths: laneBase numbers the lanes of the pair 0..127; hvBefore = the scan value of the last lane of the
-        // window before (its run may go on into this window)
-        auto pw_lengths = [&](PW &W, const int p0w, const int laneBase, const uint32_t hvBefore) {
-            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)groupLen(W.a0, W.b0));
-            if (W.twoRounds) {
-                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)groupLen(W.a1, W.b1));
-                if (W.rank4 >= 256u) r = r1;
-            }
-#ifdef ENC_STATS
-            est[7] += (unsigned)__builtin_popcountll(W.headm);
-#endif
-#ifndef ENC_EXP_NOMORE
-            if (W.headm >> 32 && __builtin_popcountll(W.headm) > 32) r = more_rounds(p0w, W.headm, W.head, W.rank4, W.cand, r);
-#endif
-            const uint32_t mine = W.head ? (((uint32_t)(laneBase + lane) + 1u) << 16) | r : 0u;
-            W.hv = max(enc_scan_max(mine), hvBefore);
-            W.delta = laneBase + lane + 1 - (int)(W.hv >> 16);
-            const int m0 = (int)(W.hv & 0xffu) - W.delta;
-            const bool hit = W.candOk && ((W.hv >> 12) & 1u) && m0 >= LZ4_MINMATCH;
-            W.myMl = hit ? (uint32_t)m0 : 0u;
-        };
-        // greedy selection in this window, continuing from pEnd (the end of the last selected match so far)
-        auto pw_select = [&](PW &W, const int p0w, int &pEnd) {
-            const bool hit = W.myMl != 0u;
-            uint64_t hitm = __ballot(hit);
-            const uint64_t capm = __ballot(hit && ((W.hv >> 13) & 1u));
-            const int lowcut = pEnd - p0w;
-            if (lowcut > 0) hitm = (lowcut >= LZ4_WAVE) ? 0ull : (hitm & (~0ull << lowcut));
-            uint64_t selm = 0;
-            int prevEnd = pEnd;
-            bool longBefore = false;
-            for (uint64_t hm = hitm; hm;) {
-                const int k = (int)__builtin_ctzll(hm);
-                int len = __builtin_amdgcn_readlane((int)W.myMl, k);
-                if ((capm >> k) & 1ull) {
-                    len += extend_long(p0w + k + len, __builtin_amdgcn_readlane((int)W.cand, k) + len);
-                    if (lane == k) W.myMl = (uint32_t)len;
-                }
-                const int endk = p0w + k + len;
-                selm |= 1ull << k;
-                pEnd = endk;
-                if (lane > k) { prevEnd = endk; longBefore = len >= ENC_END2_MINLEN; }
-                const int sh = endk - p0w;
-                hm = (sh >= LZ4_WAVE) ? 0ull : (hm & (~0ull << sh));
-            }
-            W.selm = selm;
-            W.prevEnd = prevEnd;
-            W.keep2 = longBefore;
-        };
-        // positions strictly inside a selected match take their insertion back if the bucket still holds it
-        auto pw_takeback = [&](PW &W, const int p0w) {
-            const int myPos = p0w + lane;
-            if (!((W.selm >> lane) & 1ull) && myPos < W.prevEnd && !(W.keep2 && myPos == W.prevEnd - 2)) {
-                const uint32_t h = W.hx >> 4;
-                if (table[h] == (TabT)myPos) {
-                    const uint32_t tsh = (W.hx >> 2) & 28u;
-                    table[h] = (TabT)W.oldp;
-                    lds_mskor(&tags[W.hx >> 7], 15u << tsh, ((W.tagWord >> tsh) & 15u) << tsh);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        };
+        auto pair_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 >= 8 && p0 + 200 <= n && pipeFits; };
         auto pair_window = [&](const int p0) -> int {
             const int p1 = p0 + LZ4_WAVE;
+            const uint32_t pos0 = (uint32_t)(p0 + lane), pos1 = pos0 + 64u;
             if (pfPos != p0 || pfPosB != p0) {
-                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(p0 + lane));
-                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(p1 + lane));
+                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos0);
+                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos1);
             }
-            PW W0, W1;
-            pw_probe(W0, p0, pfV8);
-            pw_probe(W1, p1, pfV8b);
-            tail_issue();                                      // the pair before this one: its cross-lane moves ride along
-            pw_heads(W0, p0, 0xffffffffu);
-            pw_heads(W1, p1, (uint32_t)__builtin_amdgcn_readlane((int)W0.cv, 63));
-            pw_loads(W0, p0);
-            pw_loads(W1, p1);
+            LW W0, W1;
+            lw_probe(W0, pos0, pfV8, true);
+            lw_probe(W1, pos1, pfV8b, true);
+            lw_heads(W0, pos0, pos0 - 8u, 0xfffffffeu);
+            lw_heads(W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.cv, 63));   // (lane 0 continues the run of the last lane of the window before it)
+            lw_loads(W0, p0);
+            lw_loads(W1, p1);
             ENC_LAP(0);
-            tail_commit();
+            commit_pending();                                  // the pair before this one: its moves' results are looked at now
             int pEnd = anchor;
-            pw_lengths(W0, p0, 0, 0u);
-            pw_select(W0, p0, pEnd);
-            pw_lengths(W1, p1, LZ4_WAVE, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
-            pw_select(W1, p1, pEnd);
+            lw_lengths(W0, p0, pos0, hc0, (uint32_t)lane + 8u, 0u);
+            const uint64_t sel0 = lw_select(W0, p0, pEnd);
+            const int pMid = pEnd;
+            lw_lengths(W1, p1, pos1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
+            const uint64_t sel1 = lw_select(W1, p1, pEnd);
             ENC_LAP(1);
             // the next pair starts at the end of the last match, or where this one ends: its bytes are requested now
             const int nextP = max(p0 + 2 * LZ4_WAVE, pEnd);
@@ -827,14 +747,16 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 pfPos = -1;
             }
             ENC_LAP(2);
-            pw_takeback(W1, p1);
-            pw_takeback(W0, p0);
+            if (qCnt + (int)__builtin_popcountll(sel0) + (int)__builtin_popcountll(sel1) > LZ4_WAVE) flush_queue();
+            const bool cov0 = lw_finish(W0, pos0, pos0 - 8u, (uint32_t)lane + 1u, sel0, anchor, 0);
+            const bool cov1 = lw_finish(W1, pos1, pos1 - 8u, (uint32_t)lane + 65u, sel1, pMid, 1);
+            // positions strictly inside a selected match take their insertion back if the bucket still holds it
+            if (cov1) lw_takeback(W1, pos1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (cov0) lw_takeback(W0, pos0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
-            tl[0].selm = W0.selm; tl[0].p0 = p0; tl[0].prevEnd = W0.prevEnd; tl[0].ml = (int)W0.myMl; tl[0].cand = W0.cand;
-            tl[0].back = W0.delta + (int)((W0.hv >> 8) & 15u);
-            tl[1].selm = W1.selm; tl[1].p0 = p1; tl[1].prevEnd = W1.prevEnd; tl[1].ml = (int)W1.myMl; tl[1].cand = W1.cand;
-            tl[1].back = W1.delta + (int)((W1.hv >> 8) & 15u);
-            if (W0.selm | W1.selm) { anchor = pEnd; missAcc = miss0; }
+            if (sel0 | sel1) { anchor = pEnd; missAcc = miss0; }
             else { missAcc += 2 * LZ4_WAVE; pfPos = -1; }
 #ifdef ENC_STATS
             est[6] += 2;
@@ -855,7 +777,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     } else {
                         do np = group_window(np); while (pipe_can_issue(np));
                     }
-                    window_tail();
+                    commit_pending();
                     p = np;
                     continue;
                 }
@@ -1015,7 +937,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     const int r1 = __builtin_amdgcn_ds_permute(dest << 2, mstart);
                     const int r2 = __builtin_amdgcn_ds_permute(dest << 2, myEnd - mstart);
                     const int r3 = __builtin_amdgcn_ds_permute(dest << 2, mstart - mcand);
-                    if (lane >= qCnt && lane < qCnt + k) { qPrev = r0; qStart = r1; qLen = r2; qOff = r3; }
+                    if (lane >= qCnt && lane < qCnt + k) {
+                        if (SMALLQ) { q0 = r0 | (r1 << 16); q1 = r2 | (r3 << 16); }
+                        else { q0 = r0; q1 = r1; q2 = r2; q3 = r3; }
+                    }
                     qCnt += k;
                 }
                 anchor = lastEnd;
@@ -1087,8 +1012,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #endif
             // ---- queue the sequence (written out by flush_queue) ----
             if (qCnt == LZ4_WAVE) flush_queue();
-            if (lane == qCnt) { qPrev = anchor; qStart = mpos; qLen = ml; qOff = mpos - cpos; }
-            qCnt++;
+            park_uniform(anchor, mpos, ml, mpos - cpos);
             anchor = mpos + ml;
             p = anchor;
             missAcc = miss0;
