@@ -172,6 +172,44 @@ __device__ __forceinline__ uint32_t enc_quad_min(uint32_t g)
     return r;
 }
 
+// Greedy selection over one window's hit mask, the scalar way: take the first hit lane, read the END of its match from
+// that lane (endv), continue with the hit lanes at or behind that end.  hm: hit lanes still in play (0 on return unless a
+// lane of capm came up: that lane's number is returned in kcap, untouched, for the caller to extend); selm gathers the
+// lanes taken, pEnd the end of the last one.  Written out because the loop is the scalar unit's largest item per
+// window: 11 scalar instructions and one v_readlane per match (the compiler's form of the same loop: 22).
+__device__ __forceinline__ void enc_select_run(uint64_t &hm, uint64_t &selm, int &pEnd, int &kcap, const uint64_t capm, const int endv, const int p0w)
+{
+    int k, endk, sh;
+    uint64_t tmp;
+    asm("s_mov_b32 %3, -1\n\t"
+        "s_cmp_eq_u64 %0, 0\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"
+        "s_ff1_i32_b64 %4, %0\n\t"
+        "s_bitcmp1_b64 %8, %4\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_readlane_b32 %5, %9, %4\n\t"
+        "s_bitset1_b64 %1, %4\n\t"
+        "s_sub_i32 %6, %5, %10\n\t"
+        "s_mov_b32 %2, %5\n\t"
+        "s_cmp_gt_i32 %6, 63\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        "s_bfm_b64 %7, %6, 0\n\t"
+        "s_andn2_b64 %0, %0, %7\n\t"
+        "s_cmp_lg_u64 %0, 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_branch 2f\n"
+        "3:\n\t"
+        "s_mov_b32 %3, %4\n\t"
+        "s_branch 2f\n"
+        "4:\n\t"
+        "s_mov_b64 %0, 0\n"
+        "2:\n"
+        : "+s"(hm), "+s"(selm), "+s"(pEnd), "=&s"(kcap), "=&s"(k), "=&s"(endk), "=&s"(sh), "=&s"(tmp)
+        : "s"(capm), "v"(endv), "s"(p0w)
+        : "scc");
+}
+
 // diagnostics (ENC_STATS builds only): cycles per phase of the dense-window path
 #ifdef ENC_STATS
 #define ENC_LAP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); est[i] += now_ - etm; etm = now_; } while (0)
@@ -485,8 +523,8 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         struct LW {
             uint32_t hx, oldp, tagWord, tmask, tbits;   // probe: hash bits, the bucket's entry and tag word as found, this position's tag in place
             uint32_t c8, cv;                            // candidate - 8; the same or ~1 without a candidate
-            bool candOk, head, twoRounds;
-            uint64_t headm;
+            bool twoRounds;
+            uint64_t candm, headm;                      // lanes with a candidate (right tag, 8 <= candidate < position); run heads among them
             uint32_t rank4, gi0;
             dev_v4 a0, b0, a1, b1;
             uint32_t hv;                                // (head idx + 1) << 16 | back << 8 | t + head idx, of the run this lane belongs to
@@ -509,28 +547,29 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
         };
         auto lw_heads = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t cvBefore) {
-            const bool tagOk = (W.tagWord & W.tmask) == W.tbits;
+            // (predicates are kept as scalar masks -- one compare each, combined by the scalar unit -- and turned back
+            // into lane predicates where a select needs them)
+            uint64_t okm = enc_ballot((W.tagWord & W.tmask) == W.tbits);
             uint32_t c8;
-            bool ok;
             if (DICT || sizeof(TabT) != 2) {
                 uint32_t cand = 0;
-                ok = tab_candidate<TabT, DICT>((TabT)W.oldp, (int)pos, cand) && cand >= 8u;
+                okm &= enc_ballot(tab_candidate<TabT, DICT>((TabT)W.oldp, (int)pos, cand));
+                okm &= enc_ballot(cand >= 8u);
                 c8 = cand - 8u;
             } else {
                 c8 = W.oldp - 8u;                                  // positions stay below 64 Ki: the entry IS the position,
-                ok = c8 < pos8;                                    // and 8 <= cand < pos in one unsigned compare (:1003-1006)
+                okm &= enc_ballot(c8 < pos8);                      // and 8 <= cand < pos in one unsigned compare (:1003-1006)
             }
-            W.candOk = tagOk && ok;
+            W.candm = okm;
             W.c8 = c8;
             // run heads: a candidate that continues its left neighbour's belongs to the same copied region
-            W.cv = W.candOk ? c8 : 0xfffffffeu;
+            W.cv = __builtin_amdgcn_inverse_ballot_w64(okm) ? c8 : 0xfffffffeu;
             const uint32_t prevC = (uint32_t)__builtin_amdgcn_update_dpp((int)cvBefore, (int)W.cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            W.head = W.candOk && c8 != prevC + 1u;
-            W.headm = enc_ballot(W.head);
+            W.headm = okm & enc_ballot(c8 != prevC + 1u);
             W.twoRounds = __builtin_popcountll(W.headm) > 16;
             W.rank4 = enc_mbcnt(W.headm) << 4;                     // byte address of lane 4 * rank
             // heads 0..15, one per group of four lanes (lane 1 takes what the others send)
-            const int dest = (W.head && W.rank4 < 256u) ? (int)W.rank4 : 4;
+            const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot(W.rank4 < 256u)) ? (int)W.rank4 : 4;
             W.gi0 = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | c8));
         };
         // a group's requests.  A group without a head decodes lane 0, candidate 8: bytes that are there (p0w >= 8)
@@ -542,7 +581,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         auto lw_loads = [&](LW &W, const int p0w) {
             lw_fetch(W.gi0, p0w, W.a0, W.b0);
             if (W.twoRounds) {                                     // heads 16..31 (one window in four has them)
-                const int dest = (W.head && (W.rank4 >> 8) == 1u) ? (int)(W.rank4 & 255u) : 4;
+                const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot((W.rank4 >> 8) == 1u)) ? (int)(W.rank4 & 255u) : 4;
                 lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, W.a1, W.b1);
             }
         };
@@ -552,7 +591,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         auto more_rounds = [&](const LW &W, const int p0w, uint32_t r) -> uint32_t {
             const int nH = (int)__builtin_popcountll(W.headm);
             for (int rr = 2; rr * 16 < nH; rr++) {
-                const int dest = (W.head && (int)(W.rank4 >> 8) == rr) ? (int)(W.rank4 & 255u) : 4;
+                const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot((int)(W.rank4 >> 8) == rr)) ? (int)(W.rank4 & 255u) : 4;
                 dev_v4 a, b;
                 lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, a, b);
                 const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(a, b));
@@ -575,14 +614,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             // every lane learns its run's head with a max-scan: head lanes put their index above their result, the others 0,
             // and the largest value at or below a lane belongs to the nearest head below it.  The low byte is t + head idx,
             // so that a lane's own length is one subtraction: (t - 8) - (idx - head idx).
-            W.hv = max(enc_scan_max(W.head ? r + headConst : 0u), hvBefore);
+            W.hv = max(enc_scan_max(__builtin_amdgcn_inverse_ballot_w64(W.headm) ? r + headConst : 0u), hvBefore);
             const int m0 = (int)(W.hv & 0xffu) - (int)idx8;
-            const bool hit = W.candOk && m0 >= LZ4_MINMATCH;
             W.m0 = (uint32_t)m0;
             W.endv = (int)pos + m0;
-            W.hitm = enc_ballot(hit);
+            W.hitm = W.candm & enc_ballot(m0 >= LZ4_MINMATCH);
             // ... and whether its run reached the horizon: t = 64
-            W.capm = enc_ballot(hit && (W.hv & 0xffu) - (W.hv >> 16) == 63u);
+            W.capm = W.hitm & enc_ballot((W.hv & 0xffu) - (W.hv >> 16) == 63u);
         };
         // greedy selection in this window, continuing from pEnd (the end of the last selected match so far): scalar, one
         // v_readlane per match taken
@@ -591,15 +629,16 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const int lowcut = pEnd - p0w;
             if (lowcut > 0) hm = (lowcut >= LZ4_WAVE) ? 0ull : (hm & (~0ull << lowcut));
             uint64_t selm = 0;
-            while (hm) {
-                const int k = (int)__builtin_ctzll(hm);
+            for (;;) {
+                int k;
+                enc_select_run(hm, selm, pEnd, k, W.capm, W.endv, p0w);
+                if (k < 0) break;
+                // lane k's run reached the horizon: the whole wave counts on
                 int endk = __builtin_amdgcn_readlane(W.endv, k);
-                if ((W.capm >> k) & 1ull) {
-                    const int ce = __builtin_amdgcn_readlane((int)W.c8, k) + 8 + (endk - (p0w + k));
-                    endk += extend_long(endk, ce);
-                    W.endv = enc_writelane(W.endv, endk, k);
-                    W.m0 = (uint32_t)enc_writelane((int)W.m0, 63, k);        // (any length from ENC_END2_MINLEN up: an inline constant)
-                }
+                const int ce = __builtin_amdgcn_readlane((int)W.c8, k) + 8 + (endk - (p0w + k));
+                endk += extend_long(endk, ce);
+                W.endv = enc_writelane(W.endv, endk, k);
+                W.m0 = (uint32_t)enc_writelane((int)W.m0, 63, k);        // (any length from ENC_END2_MINLEN up: an inline constant)
                 selm |= 1ull << k;
                 pEnd = endk;
                 const int sh = endk - p0w;
@@ -625,7 +664,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const uint32_t start = pos - back, mlen = (uint32_t)W.endv - start, off = pos8 - W.c8;
             const int k = (int)__builtin_popcountll(selm);
             const int trash = ((qCnt + 40) & 63) << 2;              // a slot outside [qCnt, qCnt + k): k <= 17
-            const int dest = sel ? (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(selm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)selm, (uint32_t)qCnt)) << 2) : trash;
+            uint32_t slot4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(selm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)selm, (uint32_t)qCnt)) << 2;
+            asm("" : "+v"(slot4));                                  // (computed for every lane: one select below, no branch around it)
+            const int dest = sel ? (int)slot4 : trash;
             if (SMALLQ) {
                 pendR[slot][0] = __builtin_amdgcn_ds_permute(dest, (int)(P | (start << 16)));
                 pendR[slot][1] = __builtin_amdgcn_ds_permute(dest, (int)(mlen | (off << 16)));
@@ -707,16 +748,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // (oracle/sim_encode2.c).  The template parameter PAIR picks the form: blocks above 64 KiB, whose positions are
         // modular, and segments run one window per step.
         // ===================================================================================================
-        uint64_t pfV8b = 0;                                  // the second window's bytes (window at pfPos + 64)
-        int pfPosB = -2;                                     // ... valid when pfPosB == pfPos (only this form requests them)
+        uint64_t pfV8b = 0;                                  // the second window's bytes
         auto pair_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 >= 8 && p0 + 200 <= n && pipeFits; };
-        auto pair_window = [&](const int p0) -> int {
+        // (the caller has the pair's bytes in pfV8 / pfV8b; go = the next pair can start at the returned position, and its
+        // bytes are on their way)
+        auto pair_window = [&](const int p0, bool &go) -> int {
             const int p1 = p0 + LZ4_WAVE;
             const uint32_t pos0 = (uint32_t)(p0 + lane), pos1 = pos0 + 64u;
-            if (pfPos != p0 || pfPosB != p0) {
-                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos0);
-                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos1);
-            }
             LW W0, W1;
             lw_probe(W0, pos0, pfV8, true);
             lw_probe(W1, pos1, pfV8b, true);
@@ -735,16 +773,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             ENC_LAP(1);
             // the next pair starts at the end of the last match, or where this one ends: its bytes are requested now
             const int nextP = max(p0 + 2 * LZ4_WAVE, pEnd);
-            pfPos = nextP;
-            pfPosB = -2;
-            if (nextP + 136 <= n) {
+            go = nextP + 200 <= n && (sel0 | sel1) != 0ull;
+            pfPos = -1;                                        // (the windows that follow the last pair fetch their own bytes)
+            if (go) {
                 pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
                 pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + LZ4_WAVE + lane));
-                pfPosB = nextP;
-            } else if (nextP + 72 <= n) {
-                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
-            } else {
-                pfPos = -1;
             }
             ENC_LAP(2);
             if (qCnt + (int)__builtin_popcountll(sel0) + (int)__builtin_popcountll(sel1) > LZ4_WAVE) flush_queue();
@@ -757,7 +790,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
             if (sel0 | sel1) { anchor = pEnd; missAcc = miss0; }
-            else { missAcc += 2 * LZ4_WAVE; pfPos = -1; }
+            else missAcc += 2 * LZ4_WAVE;
 #ifdef ENC_STATS
             est[6] += 2;
 #endif
@@ -773,7 +806,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     int np = (int)p;
                     if constexpr (PAIR) {
                         // (the last 200 bytes of a block are left to the windows below)
-                        while (pair_can_issue(np)) np = pair_window(np);
+                        if (pfPos != np) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + lane));
+                        pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + LZ4_WAVE + lane));
+                        bool go = true;
+                        do np = pair_window(np, go); while (go);
                     } else {
                         do np = group_window(np); while (pipe_can_issue(np));
                     }
