@@ -151,6 +151,12 @@ __device__ __forceinline__ void lds_mskor(uint32_t *w, uint32_t mask, uint32_t b
 {
     asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"((uint32_t)(uintptr_t)w), "v"(mask), "v"(bits) : "memory");
 }
+// the same on the tag word `idx` of the table that starts at `table`: the tags' distance from the table (4096 16-bit
+// positions) travels in the instruction's offset field, so the word's address is the one its read already computed
+__device__ __forceinline__ void lds_mskor_tag(const void *table, uint32_t idx, uint32_t mask, uint32_t bits)
+{
+    asm volatile("ds_mskor_b32 %0, %1, %2 offset:8192" : : "v"((uint32_t)(uintptr_t)table + idx * 4u), "v"(mask), "v"(bits) : "memory");
+}
 
 // v_writelane_b32: lane k of v becomes the wave-uniform x.  (This clang has no builtin for it; the LLVM intrinsic is
 // reached by name, and the compiler then takes care of gfx9's rule that the lane select travels in M0 when the value
@@ -383,7 +389,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             qCnt = 0;
             return;
         }
+#ifndef ENC_EXP_NOEMIT
         op = emit_sequences(src, op, qPrev, qStart, qLen, qOff, qCnt);
+#else
+        if (lane == 0) *(volatile int *)op = qPrev + qStart + qLen + qOff;      // (experiment: what the emission costs)
+#endif
         qCnt = 0;
     };
     // one sequence whose fields are wave-uniform, into slot qCnt (the caller has made room)
@@ -475,8 +485,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         const bool pipeFits = n < (1 << 24);           // a group's candidate travels in 25 bits, an end in 24
         // lane constants of the groups: lane j of a group holds bytes [16 j - 8, 16 j + 8) relative to the head
         const uint32_t j4 = (uint32_t)lane & 3u;
-        const uint32_t gc0 = j4 << 7, gc1 = gc0 | 32u, gc2 = gc0 | 64u, gc3 = gc0 | 96u;    // bit offsets of a lane's four words
-        const uint32_t fwdMask = j4 ? 0xffffffffu : 0u;       // a group's lane 0: its first 8 bytes lie BEFORE the head
+        // bit offsets of a lane's four words; a group's lane 0 holds the 8 bytes BEFORE the head in its first two: ~0 keeps
+        // them out of the minimum
+        const uint32_t gc0 = j4 ? j4 << 7 : 0xffffffffu, gc1 = j4 ? (j4 << 7) | 32u : 0xffffffffu, gc2 = (j4 << 7) | 64u, gc3 = (j4 << 7) | 96u;
         const uint32_t j16 = j4 << 4;
         const uint32_t lanePay = (uint32_t)lane << 25;        // a head's message to its group: lane | candidate - 8
 
@@ -487,9 +498,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // the group is the first differing bit of its 512 (or ~0).
         auto group_len = [&](const dev_v4 &a, const dev_v4 &b) -> uint32_t {
             const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-            uint32_t g = min(min(ffbl32(x0 & fwdMask) | gc0, ffbl32(x1 & fwdMask) | gc1), min(ffbl32(x2) | gc2, ffbl32(x3) | gc3));
-            g = enc_quad_min(g);
-            const uint32_t t = min(g >> 3, 64u);
+            uint32_t g = min(min(ffbl32(x0) | gc0, ffbl32(x1) | gc1), ffbl32(x2) | gc2);
+            g = enc_quad_min(min(min(g, ffbl32(x3) | gc3), 512u));             // (512: nothing differs within the horizon)
+            const uint32_t t = g >> 3;
             const uint32_t back = min(min(ffbh32(x1), ffbh32(x0) | 32u) >> 3, 8u);
             return t | (back << 8);
         };
@@ -522,11 +533,12 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // One window's state.  Lane l stands for position p0w + l; idx = l (+ 64 in the second window of a pair).
         struct LW {
             uint32_t hx, oldp, tagWord, tmask, tbits;   // probe: hash bits, the bucket's entry and tag word as found, this position's tag in place
-            uint32_t c8, cv;                            // candidate - 8; the same or ~1 without a candidate
+            uint32_t c8, off;                           // candidate - 8; position - candidate
             bool twoRounds;
             uint64_t candm, headm;                      // lanes with a candidate (right tag, 8 <= candidate < position); run heads among them
             uint32_t rank4, gi0;
             dev_v4 a0, b0, a1, b1;
+            uint32_t r;                                 // head lanes: their group's result (group_len)
             uint32_t hv;                                // (head idx + 1) << 16 | back << 8 | t + head idx, of the run this lane belongs to
             uint32_t m0;                                // hit lanes: match length from this lane on (0..56; 63 once extended)
             int endv;                                   // hit lanes: end of that match
@@ -542,11 +554,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             W.tagWord = tags[hx >> 7];
             if (insertNow) {                                       // every position, at once: the window behind this one probes next
                 table[hx >> 4] = (TabT)pos;
-                lds_mskor(&tags[hx >> 7], W.tmask, W.tbits);
+                lds_mskor_tag(table, hx >> 7, W.tmask, W.tbits);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         };
-        auto lw_heads = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t cvBefore) {
+        auto lw_heads = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t offBefore, const uint64_t okBefore) {
             // (predicates are kept as scalar masks -- one compare each, combined by the scalar unit -- and turned back
             // into lane predicates where a select needs them)
             uint64_t okm = enc_ballot((W.tagWord & W.tmask) == W.tbits);
@@ -562,10 +574,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             W.candm = okm;
             W.c8 = c8;
-            // run heads: a candidate that continues its left neighbour's belongs to the same copied region
-            W.cv = __builtin_amdgcn_inverse_ballot_w64(okm) ? c8 : 0xfffffffeu;
-            const uint32_t prevC = (uint32_t)__builtin_amdgcn_update_dpp((int)cvBefore, (int)W.cv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            W.headm = okm & enc_ballot(c8 != prevC + 1u);
+            // run heads: a candidate that continues its left neighbour's -- the same distance back, and the neighbour has a
+            // candidate -- belongs to the same copied region
+            W.off = pos8 - c8;
+            const uint32_t offLeft = (uint32_t)__builtin_amdgcn_update_dpp((int)offBefore, (int)W.off, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            W.headm = okm & ~(enc_ballot(W.off == offLeft) & ((okm << 1) | okBefore));
             W.twoRounds = __builtin_popcountll(W.headm) > 16;
             W.rank4 = enc_mbcnt(W.headm) << 4;                     // byte address of lane 4 * rank
             // heads 0..15, one per group of four lanes (lane 1 takes what the others send)
@@ -599,9 +612,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             return r;
         };
-        // lengths: headConst = (idx + 1) << 16 | idx, idx8 = idx + 8; hvBefore = the scan value of the last lane of the
-        // window before (its run may go on into this one)
-        auto lw_lengths = [&](LW &W, const int p0w, const uint32_t pos, const uint32_t headConst, const uint32_t idx8, const uint32_t hvBefore) {
+        // lengths, in two steps so that a pair's two cross-lane reads travel together.  lw_measure: each head lane fetches its
+        // group's result (W.r).  lw_hits: headConst = (idx + 1) << 16 | idx, idx8 = idx + 8; hvBefore = the scan value of the
+        // last lane of the window before (its run may go on into this one)
+        auto lw_measure = [&](LW &W, const int p0w) {
             uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a0, W.b0));
             if (W.twoRounds) {
                 const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a1, W.b1));
@@ -611,13 +625,17 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             est[7] += (unsigned)__builtin_popcountll(W.headm);
 #endif
             if (__builtin_popcountll(W.headm) > 32) r = more_rounds(W, p0w, r);
+            W.r = r;
+        };
+        auto lw_hits = [&](LW &W, const int p0w, const uint32_t headConst, const uint32_t idx8, const uint32_t hvBefore) {
             // every lane learns its run's head with a max-scan: head lanes put their index above their result, the others 0,
             // and the largest value at or below a lane belongs to the nearest head below it.  The low byte is t + head idx,
             // so that a lane's own length is one subtraction: (t - 8) - (idx - head idx).
-            W.hv = max(enc_scan_max(__builtin_amdgcn_inverse_ballot_w64(W.headm) ? r + headConst : 0u), hvBefore);
-            const int m0 = (int)(W.hv & 0xffu) - (int)idx8;
+            W.hv = max(enc_scan_max(__builtin_amdgcn_inverse_ballot_w64(W.headm) ? W.r + headConst : 0u), hvBefore);
+            const uint32_t E = W.hv & 0xffu;                      // t + head idx
+            const int m0 = (int)E - (int)idx8;
             W.m0 = (uint32_t)m0;
-            W.endv = (int)pos + m0;
+            W.endv = (int)E + (p0w - 8 - (int)(idx8 - 8u - (uint32_t)lane));        // position + m0 (the bracket is wave-uniform)
             W.hitm = W.candm & enc_ballot(m0 >= LZ4_MINMATCH);
             // ... and whether its run reached the horizon: t = 64
             W.capm = W.hitm & enc_ballot((W.hv & 0xffu) - (W.hv >> 16) == 63u);
@@ -661,7 +679,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             // head's group measured up to 8 more before the head
             const uint32_t backAvail = (idx1 - (W.hv >> 16)) + ((W.hv >> 8) & 15u);
             const uint32_t back = min(min(backAvail, pos - P), W.c8);
-            const uint32_t start = pos - back, mlen = (uint32_t)W.endv - start, off = pos8 - W.c8;
+            const uint32_t start = pos - back, mlen = (uint32_t)W.endv - start, off = W.off;
             const int k = (int)__builtin_popcountll(selm);
             const int trash = ((qCnt + 40) & 63) << 2;              // a slot outside [qCnt, qCnt + k): k <= 17
             uint32_t slot4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(selm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)selm, (uint32_t)qCnt)) << 2;
@@ -683,12 +701,12 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // this position into its bucket / the bucket's entry as found put back if it still holds this position
         auto lw_insert = [&](const LW &W, const uint32_t pos) {
             table[W.hx >> 4] = (TabT)pos;
-            lds_mskor(&tags[W.hx >> 7], W.tmask, W.tbits);
+            lds_mskor_tag(table, W.hx >> 7, W.tmask, W.tbits);
         };
-        auto lw_takeback = [&](const LW &W, const uint32_t pos) {
-            if (table[W.hx >> 4] == (TabT)pos) {
+        auto lw_takeback = [&](const LW &W, const uint32_t pos, const uint32_t now) {
+            if (now == (pos & (uint32_t)(TabT)~(TabT)0)) {
                 table[W.hx >> 4] = (TabT)W.oldp;
-                lds_mskor(&tags[W.hx >> 7], W.tmask, W.tagWord & W.tmask);
+                lds_mskor_tag(table, W.hx >> 7, W.tmask, W.tagWord & W.tmask);
             }
         };
         const uint32_t hc0 = (((uint32_t)lane + 1u) << 16) | (uint32_t)lane, hc1 = hc0 + ((64u << 16) | 64u);
@@ -702,11 +720,12 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos);
             LW W;
             lw_probe(W, pos, pfV8, false);
-            lw_heads(W, pos, pos8, 0xfffffffeu);
+            lw_heads(W, pos, pos8, 0u, 0ull);
             lw_loads(W, p0);
             ENC_LAP(0);
             commit_pending();                                  // (the requests are out: the last window's moves are looked at now)
-            lw_lengths(W, p0, pos, hc0, (uint32_t)lane + 8u, 0u);
+            lw_measure(W, p0);
+            lw_hits(W, p0, hc0, (uint32_t)lane + 8u, 0u);
             if (!W.hitm) {
                 // nothing here: every position is registered, the miss counter widens the stride (:957-967)
                 lw_insert(W, pos);
@@ -758,17 +777,19 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             LW W0, W1;
             lw_probe(W0, pos0, pfV8, true);
             lw_probe(W1, pos1, pfV8b, true);
-            lw_heads(W0, pos0, pos0 - 8u, 0xfffffffeu);
-            lw_heads(W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.cv, 63));   // (lane 0 continues the run of the last lane of the window before it)
+            lw_heads(W0, pos0, pos0 - 8u, 0u, 0ull);
+            lw_heads(W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63);   // (lane 0 may continue the run of the last lane of the window before it)
             lw_loads(W0, p0);
             lw_loads(W1, p1);
             ENC_LAP(0);
             commit_pending();                                  // the pair before this one: its moves' results are looked at now
             int pEnd = anchor;
-            lw_lengths(W0, p0, pos0, hc0, (uint32_t)lane + 8u, 0u);
+            lw_measure(W0, p0);
+            lw_measure(W1, p1);
+            lw_hits(W0, p0, hc0, (uint32_t)lane + 8u, 0u);
             const uint64_t sel0 = lw_select(W0, p0, pEnd);
             const int pMid = pEnd;
-            lw_lengths(W1, p1, pos1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
+            lw_hits(W1, p1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
             const uint64_t sel1 = lw_select(W1, p1, pEnd);
             ENC_LAP(1);
             // the next pair starts at the end of the last match, or where this one ends: its bytes are requested now
@@ -784,9 +805,19 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const bool cov0 = lw_finish(W0, pos0, pos0 - 8u, (uint32_t)lane + 1u, sel0, anchor, 0);
             const bool cov1 = lw_finish(W1, pos1, pos1 - 8u, (uint32_t)lane + 65u, sel1, pMid, 1);
             // positions strictly inside a selected match take their insertion back if the bucket still holds it
-            if (cov1) lw_takeback(W1, pos1);
+            // (ENC_EXP_TAKEBACK_TOGETHER reads both buckets before either is written -- one LDS round trip for the pair; where
+            // the two windows met in ONE bucket and both positions are covered, the first window's then stays registered.
+            // Measured: lzsynth ratio 2.894 -> 2.904, encode +1 %, but the stream decodes 2 % slower: off)
+#ifdef ENC_EXP_TAKEBACK_TOGETHER
+            const uint32_t now1 = table[W1.hx >> 4], now0 = table[W0.hx >> 4];
+            if (cov1) lw_takeback(W1, pos1, now1);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (cov0) lw_takeback(W0, pos0);
+            if (cov0) lw_takeback(W0, pos0, now0);
+#else
+            if (cov1) lw_takeback(W1, pos1, table[W1.hx >> 4]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (cov0) lw_takeback(W0, pos0, table[W0.hx >> 4]);
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
             if (sel0 | sel1) { anchor = pEnd; missAcc = miss0; }

@@ -174,7 +174,11 @@ void launch_encode(const EncodeArgs &a, bool bigBlocks, hipStream_t s)
     const dim3 grid((unsigned)a.nBlocks), wg(64);
     if (bigBlocks) hipLaunchKernelGGL((k_encode<true, false>), grid, wg, 0, s, a);
     else if (a.linked) hipLaunchKernelGGL((k_encode<true, true>), grid, wg, 0, s, a);
+#ifdef ENC_EXP_NOPAIR
+    else hipLaunchKernelGGL((k_encode<false, false>), grid, wg, 0, s, a);
+#else
     else hipLaunchKernelGGL((k_encode<false, true>), grid, wg, 0, s, a);
+#endif
 }
 
 // ---------------------------------------------------------------------------
