@@ -2,6 +2,7 @@
 #
 #   make            -> streamly-lz4_amd/lib/libmi355lz4.so  + oracle/
 #   make lib        -> product library only
+#   make lib-exp    -> the same with the shelved experiments compiled in (tests only)
 #   make oracle     -> oracle/liboracle.so (+ oracle/_ref when /root/reference exists)
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
@@ -20,6 +21,15 @@ lib: $(LIB)
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -shared -Wl,-Bsymbolic -o $@ -x hip $(SRCS)
+
+# The library with the measured-and-shelved experiments compiled in (decoder variant 3: the token-list parse of round 4).
+# Not what ships: `make lib` leaves them out.  tests/test_experiment_build_gpu.py runs the decoder parity tests on it.
+LIBEXP := $(PKG)/lib/libmi355lz4_exp.so
+lib-exp: $(LIBEXP)
+
+$(LIBEXP): $(SRCS) $(HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -DMI355LZ4_EXPERIMENTS -shared -Wl,-Bsymbolic -o $@ -x hip $(SRCS)
 
 oracle:
 	$(MAKE) -C oracle
@@ -46,7 +56,7 @@ tsan: build/san/host_tsan
 
 clean:
 	rm -rf build/san
-	rm -f $(LIB)
+	rm -f $(LIB) $(LIBEXP)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean asan tsan
+.PHONY: all lib lib-exp oracle clean asan tsan

@@ -607,16 +607,35 @@ def main():
         line["incompressible"] = incompressible_rates(S, eng, torch, dev)
     if world == 1 and not args.no_host_api and kind != "canterbury-large":
         line["host_api_pcie_inclusive"] = host_api_rates(S, eng, src, BL, kind)
+    gather_failed = False
     if gather is not None:
-        # compute-only is `value`; compute+gather adds one ordered gather per compress pass
+        # compute-only is `value` (N x one GPU by construction: no collective in the timed region).  The numbers that
+        # test the multi-GPU design are the gather's own: what the root RECEIVES (the peers' framed bytes: (N - 1) / N of
+        # the gathered stream) over its time, against the root's seven xGMI links (7 x 153 GB/s, MI355X_MICROARCH.md), and the
+        # round trip with one ordered gather per pass added to it.
         cm = (extra or {}).get("kernels_ms", {}).get("compress")
+        if "ms" in gather and gather.get("bytes"):
+            recv = gather["bytes"] * (world - 1) / world
+            gather["received_bytes"] = int(recv)
+            gather["GBps"] = round(recv / gather["ms"] / 1e6, 2)
+            gather["xgmi_peak_GBps"] = 7 * 153.0
+            gather["frac_of_xgmi_peak"] = round(recv / gather["ms"] / 1e6 / (7 * 153.0), 4)
         if cm and "ms" in gather:
             gather["compress_only_GBps"] = round(world * U / cm / 1e6, 2)
             gather["compress_plus_gather_GBps"] = round(world * U / (cm + gather["ms"]) / 1e6, 2)
+        if extra is not None and "ms" in gather:
+            line["roundtrip_plus_gather_GBps"] = round(world * U / (extra["roundtrip_ms_per_step"] + gather["ms"]) / 1e6, 2)
+        gather["note"] = ("no RCCL rank had run this code before the first driver SCALE run: the gather is covered by gloo "
+                          "tests with 2 and 3 ranks and a gloo rehearsal on one GPU")
         line["gather"] = gather
+        if gather.get("error") or gather.get("verified") is False:
+            line["verified"] = False            # a wrong or failed ordered gather fails the run (exit code 1 below)
+            gather_failed = True
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if gather_failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

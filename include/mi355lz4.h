@@ -117,11 +117,8 @@ int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
  * slot used longest ago) until mi355lz4_destroy; automatic mode leaves the path alone once that scratch would pass
  * 1 GiB, a forced count does not. */
 int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
-/* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel,
- * 2 = lane-parallel kernel, 3 = experiment of round 4: token positions from a pass of its own (one lane per block
- * walks the token chain into a list), then the lane-parallel kernel driven by the list -- measured slower than 2
- * with the list pass that exists, kept as the reproducible form of that measurement.
- * Tuning/ablation knob; results are identical. */
+/* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel, 2 = lane-parallel kernel.
+ * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
 /* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block
  * i-1 as block i's dictionary whenever it lies directly in front of it in memory -- what the reference's

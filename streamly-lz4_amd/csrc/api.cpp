@@ -370,9 +370,25 @@ extern "C" int mi355lz4_synchronize(mi355lz4_ctx *c)
     return MI355LZ4_OK;
 }
 
+// 1 when the library was built with the shelved experiments (make lib-exp): the tests ask before they use variant 3.
+// Not in the public header.
+extern "C" int mi355lz4_debug_has_experiments(void)
+{
+#ifdef MI355LZ4_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
-    if (!c || variant < 0 || variant > 3) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+#ifdef MI355LZ4_EXPERIMENTS
+    const int top = 3;       // 3 = the parse as a pass of its own (token lists), experiment builds only (make lib-exp)
+#else
+    const int top = 2;
+#endif
+    if (!c || variant < 0 || variant > top) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -621,7 +637,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
-    a.tokList = nullptr; a.tokCnt = nullptr;
+    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -634,12 +650,15 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
+#ifdef MI355LZ4_EXPERIMENTS
     else if (c->decoder == 3 && dev_reserve(c->tokBuf, (size_t)(framedLen >> 1) + 192 + ((size_t)nBlocks + 1) * sizeof(int32_t)) == 0) {
         // experiment: the parse as a pass of its own (token lists), then the list-driven decoder
         a.tokCnt = (int32_t *)c->tokBuf.p;
         a.tokList = (uint8_t *)c->tokBuf.p + ((((size_t)nBlocks + 1) * sizeof(int32_t) + 63) & ~(size_t)63);
         launch_decode_tok(a, c->stream);
-    } else
+    }
+#endif
+    else
         launch_decode_par(a, c->stats, c->stream);
     if (!linked) return check_launch("decode launch");
     // Linked streams.  Whether there is a second pass at all, and over which blocks, is decided here: the
@@ -676,6 +695,11 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         const bool plain = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS");
         if (!streamFirst && !a.asyncGate && !splitOk && !deferEnd && runMax > 0 && stat[5] >= 1 && stat[5] <= runMax &&
             (envRuns || plain)) {
+            // the runs' first blocks as a list taken from the first pass's results (stat[6] = how many there are in the call)
+            const int runs = (int)stat[6] > 0 ? (int)stat[6] : 1;
+            if ((r = dev_reserve(c->tolMeta, ((size_t)runs + 1) * sizeof(int32_t)))) { link_scratch_release(c); return r; }
+            a.runList = (int32_t *)c->tolMeta.p; a.runCap = runs;
+            HIP_TRY(hipMemsetAsync(a.runList, 0, sizeof(int32_t), c->stream));
             a.segFirst = first; a.segEnd = last + 1;
             launch_linked_runs(a, c->stream);
             link_scratch_release(c);
@@ -1589,7 +1613,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.streamFirst = nullptr; a.nStreams = 0; a.lookBack = 0;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
-    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr;
+    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
     if (s->dictLen) {
         // the exact decoder with the dictionary in force, at once (a block that does not reach back decodes the same)
         if (hipMemcpyAsync(resDev, (const uint8_t *)s->inDev.p + 16, 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;

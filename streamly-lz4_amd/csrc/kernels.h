@@ -48,8 +48,12 @@ struct DecodeArgs {
     uint32_t *ptrBad;             // per stream (one entry without streamFirst): left to the serial walk
     int asyncGate;                // second-pass kernels return at once when linkStat[0] == 0 (asynchronous linked decode)
     int onlyBlk;                  // >= 0: the fetch covers this block alone (mi355lz4_decompress_linked_end_last); -1: all
-    // token lists (decode_par.hpp, LIST): block blk's list lives at tokList + blockOff[blk] / 2 (a sequence is at least
-    // three compressed bytes), tokCnt[blk] entries; both null without the list pass
+    // run starts of a linked stream's dependent blocks (k_run_starts -> k_decode_fixup_runs): runList[0] = count,
+    // runList[1..] = first block of each run, at most runCap of them; null: the launch covers one run that starts at segFirst
+    int32_t *runList;
+    int runCap;
+    // experiment builds only (MI355LZ4_EXPERIMENTS; decode_par.hpp, LIST): block blk's token list lives at tokList +
+    // blockOff[blk] / 2 (a sequence is at least three compressed bytes), tokCnt[blk] entries; both null without the list pass
     uint8_t *tokList;
     int32_t *tokCnt;
 };
@@ -85,7 +89,9 @@ struct EncodeSegArgs {
 void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s);
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
+#ifdef MI355LZ4_EXPERIMENTS
 void launch_decode_tok(const DecodeArgs &a, hipStream_t s);      // token lists (a.tokList / a.tokCnt), then the list-driven decoder
+#endif
 #define PAR_STATS_COUNT 32
 void launch_linked_tolerant(const DecodeArgs &a, hipStream_t s);   // both cover blocks [a.segFirst, a.segEnd)
 void launch_linked_resolve(const DecodeArgs &a, hipStream_t s);

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(1024) void k_link_stat(DecodeArgs a)
         int n = 1;
         while (n <= LINK_RUN_CAP && blk + n < a.nBlocks && a.result[blk + n] <= 0) n++;
         atomicMax(&a.linkStat[5], (uint32_t)n);
+        atomicAdd(&a.linkStat[6], 1u);                             // ... and how many runs there are (k_run_starts' list)
     }
     __syncthreads();
     if (tid == 0 && sh[0]) {
@@ -537,6 +538,7 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
     launch_link_stat(a, s);
 }
 
+#ifdef MI355LZ4_EXPERIMENTS
 // ---- token lists: the parse as a pass of its own (experiment of round 4) ----
 // One LANE per block walks the block's token chain (cbits/lz4.c:1801-1854: token, literal length, offset, match length)
 // and writes the compressed size of every sequence as one byte; 0 ends the list (a length that does not fit a byte, a
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(64) void k_walk_tokens(DecodeArgs a)
     if (read_block_header(a, blk, data, compLen, cap) == 0) {
         const LZ4_GLOBAL uint8_t *p = as_global(data);
         LZ4_GLOBAL uint8_t *out = as_global(a.tokList + (a.blockOff[blk] >> 1));
-        const int limit = (int)((a.blockOff[blk + 1] - a.blockOff[blk]) >> 1) - 1;
+        const int limit = ((compLen + a.headerKind) >> 1) - 1;      // the list's room: half the block's framed bytes
         int ip = 0;
         while (n < limit) {
             const int tp = ip;
@@ -602,6 +604,7 @@ void launch_decode_tok(const DecodeArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_decode_tok<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, (unsigned long long *)nullptr);
     launch_link_stat(a, s);
 }
+#endif  // MI355LZ4_EXPERIMENTS
 
 // Linked streams (reference semantics of LZ4_decompress_safe_continue with every
 // block in its own allocation, cbits/lz4.c:2347-2355): block i may reference the
@@ -652,13 +655,28 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
 // would write and chase four bytes of pointer per output byte of the whole SPAN between the first and the last dependent
 // block for them (2 ms for that sample; this: one block's latency per block of the longest run).  Chosen by the host
 // when the longest run is short (linkStat[5]); same dictionary rules as k_decode_fixup_regions (:2331-2333, :2347-2355).
+// The runs' first blocks are taken from the FIRST pass's results before any walker has changed them (k_run_starts: a
+// list).  Round 4 let every wave decide "am I a run start" from result[blk - 1] inside the walking launch: a wave
+// dispatched late could see the block in front of it already fixed by its run's walker, take itself for a run start and
+// walk the same blocks a second time, racing the first walker.  (The list also shrinks the grid to one wave per run.)
+__global__ __launch_bounds__(256) void k_run_starts(DecodeArgs a)
+{
+    const int blk = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
+    if (blk >= a.segEnd || a.result[blk] > 0) return;
+    if (blk != a.segFirst && a.result[blk - 1] <= 0) return;
+    const int i = atomicAdd(&a.runList[0], 1);
+    if (i < a.runCap) a.runList[1 + i] = blk;
+}
+
 __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
 {
     __shared__ ParLds lds;
-    const int blk = a.segFirst + (int)blockIdx.x;
+    int blk = a.segFirst;                                           // (no list: one run, the legacy face's single block)
+    if (a.runList) {
+        if ((int)blockIdx.x >= min(uni(a.runList[0]), a.runCap)) return;
+        blk = uni(a.runList[1 + blockIdx.x]);
+    } else if (blockIdx.x != 0) return;
     if (blk >= a.segEnd || uni(a.result[blk]) > 0) return;
-    // a run starts behind a block with output (or at the range's first block)
-    if (blk != a.segFirst && uni(a.result[blk - 1]) <= 0) return;
     const uint8_t *dict = nullptr;
     uint32_t dictLen = 0;
     if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
@@ -666,6 +684,7 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
         const int rj = uni(a.result[j]);
         if (rj > 0) { dict = a.out + a.outOff[j]; dictLen = (uint32_t)rj; break; }
     }
+    // (the blocks behind a run's end decoded in the first pass: no walker writes their results, reading them is safe)
     for (int f = blk; f < a.segEnd; f++) {
         int r = uni(a.result[f]);
         if (r > 0) break;                                           // the run is over
@@ -678,8 +697,8 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
                 r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed,
                                                   a.framed + a.framedLen, lds, nullptr);
             r = uni(r);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");     // the block's bytes are out before its result says so
             if (lane_id() == 0) a.result[f] = r;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         }
         if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
     }
@@ -688,7 +707,10 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
 void launch_linked_runs(const DecodeArgs &a, hipStream_t s)
 {
     const int n = a.segEnd - a.segFirst;
-    if (n > 0) hipLaunchKernelGGL(k_decode_fixup_runs, dim3((unsigned)n), dim3(64), 0, s, a);
+    if (n <= 0) return;
+    if (!a.runList) { hipLaunchKernelGGL(k_decode_fixup_runs, dim3(1), dim3(64), 0, s, a); return; }
+    hipLaunchKernelGGL(k_run_starts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_decode_fixup_runs, dim3((unsigned)min(n, a.runCap)), dim3(64), 0, s, a);
 }
 
 // Single stream (streamFirst == null): only REGIONS need the serial walk.  A region is a maximal run of

@@ -290,6 +290,16 @@ class Engine:
     def set_batch_blocks(self, n):
         lib.slz4_engine_set_batch(self._h, int(n))
 
+    @staticmethod
+    def has_experiments():
+        """True when the loaded library is the experiment build (make lib-exp): decoder variant 3 exists."""
+        try:
+            f = lib.mi355lz4_debug_has_experiments
+        except AttributeError:
+            return False
+        f.restype = C.c_int
+        return bool(f())
+
     def set_decoder(self, variant):
         _check(lib.mi355lz4_set_decoder(self.ctx, int(variant)), "set_decoder")
 

@@ -9,6 +9,33 @@ for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
         sys.path.insert(0, p)
 
 
+def _decoders():
+    """Decoder variants the loaded library has: 1 (sequence at a time), 2 (lane-parallel) and, in the experiment build
+    only (make lib-exp, MI355LZ4_LIB pointing at it), 3 (token lists).  MI355LZ4_TEST_ONLY_DECODER narrows the list."""
+    try:
+        import streamly_lz4_amd as S
+        ds = [1, 2, 3] if S.Engine.has_experiments() else [1, 2]
+    except Exception:
+        ds = [1, 2]
+    only = os.environ.get("MI355LZ4_TEST_ONLY_DECODER")
+    if only:
+        ds = [d for d in ds if d == int(only)]
+    return ds
+
+
+DECODERS = _decoders()
+
+
+def pytest_collection_modifyitems(config, items):
+    # tests/test_experiment_build_gpu.py re-runs the decoder-parametrized tests on the experiment build, variant 3 only
+    if os.environ.get("MI355LZ4_TEST_ONLY_DECODER"):
+        keep = [it for it in items if "decoder" in getattr(it, "fixturenames", ()) and hasattr(it, "callspec") and "decoder" in it.callspec.params]
+        drop = [it for it in items if it not in keep]
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = keep
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

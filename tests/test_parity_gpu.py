@@ -8,6 +8,8 @@ import random
 import numpy as np
 import pytest
 
+from conftest import DECODERS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -27,7 +29,7 @@ def split_blocks(fr, meta=8):
 # --------------------------------------------------------------------------------------------
 # decode: bit-exact vs oracle / golden
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", DECODERS)
 @pytest.mark.parametrize("kind", ["lzsynth", "text", "random"])
 def test_decode_matches_oracle(engine, oracle, kind, decoder):
     engine.set_decoder(decoder)
@@ -67,7 +69,7 @@ def test_decode_linked_fixture(engine, linked_golden):
     assert blen == [linked_golden["block_len"]] * 4 and sha(out) == linked_golden["raw_sha256"]
 
 
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", DECODERS)
 def test_decode_malformed_codes(engine, golden, decoder):
     """Negative codes -(ip-src)-1 (cbits/lz4.c:2163) equal the reference's, for both decoder kernels."""
     engine.set_decoder(decoder)
@@ -85,7 +87,7 @@ def test_decode_malformed_codes(engine, golden, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", DECODERS)
 def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
     """Mutated / truncated blocks, batched: every status and every decoded byte equals the oracle's."""
     engine.set_decoder(decoder)
@@ -122,7 +124,7 @@ def test_decode_fuzz_vs_oracle(engine, oracle, decoder):
         engine.set_decoder(0)
 
 
-@pytest.mark.parametrize("decoder", [1, 2, 3])
+@pytest.mark.parametrize("decoder", DECODERS)
 def test_decode_huge_length_fields(engine, oracle, decoder):
     """Length fields that are multi-megabyte runs of 0xFF (lengths >= 2^31): same code as the oracle, and
     nothing is written outside the block's output (cbits/lz4.c:1811-1818, 1854-1858, 2064-2065)."""
@@ -478,6 +480,25 @@ def test_roundtrip_config2_full_size(slz4, engine, oracle):
     # spot-check a few blocks of the GPU-written stream with the CPU oracle
     host_off = doff.cpu().numpy()
     for i in (0, 1, 777, 65535):
+        blk = dense[int(host_off[i]):int(host_off[i + 1])].cpu().numpy().tobytes()
+        code, out = oracle.decompress_block(blk[8:], bl)
+        assert code == bl and out == oracle.gen("lzsynth", 1, bl, first_block=i).tobytes()
+
+
+def test_roundtrip_config4_share_one_call_8GiB(slz4, engine, oracle):
+    """BASELINE config 4's per-GPU share is 64 GiB / 8 = 8 GiB: 131 072 blocks of 64 KiB compressed, compacted and decoded
+    in ONE call each -- more than 2^32 bytes of output behind one launch, which is also what the root's verification of
+    the gathered stream decodes at N = 8 (bench.py).  Identity round trip + oracle spot checks either side of 2^32."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 40 GiB of free device memory")
+    nb, bl = 131072, 65536
+    total, dense, doff = _roundtrip_device(slz4, engine, "lzsynth", nb, bl, 1)
+    assert 2.7 < nb * bl / total < 3.1
+    host_off = doff.cpu().numpy()
+    assert int(host_off[-1]) == total and nb * bl > (1 << 32)
+    for i in (0, 65535, 65536, 131071):                                          # output offsets 0, 2^32 - 64 Ki, 2^32, 2^33 - 64 Ki
         blk = dense[int(host_off[i]):int(host_off[i + 1])].cpu().numpy().tobytes()
         code, out = oracle.decompress_block(blk[8:], bl)
         assert code == bl and out == oracle.gen("lzsynth", 1, bl, first_block=i).tobytes()
