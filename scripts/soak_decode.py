@@ -55,9 +55,10 @@ while time.time() - t0 < budget:
             out, blen = eng.decompress_batch(comp_gpu)
             assert out == data, ("gpu stream", dv, bl, nb, lit_max, off_max, mlen_max, accel, cases)
     eng.set_decoder(0)
-    # the reference's linked stream through the linked decode (default path, run walker, pointer pass)
+    # the reference's linked stream through the linked decode (default path, run walker, pointer pass, twin decode with random piece lengths)
     fr_l = o.frame_compress(data, bl, accel, 8, True)
-    for env in ({}, {"MI355LZ4_LINKED_RUNS": "100000"}, {"MI355LZ4_LINKED_RUNS": "0"}):
+    for env in ({}, {"MI355LZ4_LINKED_RUNS": "100000"}, {"MI355LZ4_LINKED_RUNS": "0"},
+                {"MI355LZ4_LINKED_RUNS": "0", "MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": str(rng.choice([1, 2, 3, 16]))}):
         for k, v in env.items():
             os.environ[k] = v
         out, blen = eng.decompress_batch(fr_l, linked=True)

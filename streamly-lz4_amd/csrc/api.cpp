@@ -637,7 +637,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
-    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.twin = nullptr; a.twinStride = 0; a.seamPages = nullptr; a.twinPiece = 0; a.twinSpin = 0; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -681,7 +681,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
-    const int first = (int)stat[1], last = (int)stat[2];
+    int first = (int)stat[1], last = (int)stat[2];
     if (first < 0 || last >= nBlocks || first > last) {
         link_scratch_release(c);          // the first pass is in flight on linkBuf: the next linked call must be ordered behind it
         return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
@@ -704,6 +704,77 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             launch_linked_runs(a, c->stream);
             link_scratch_release(c);
             return check_launch("decode launch");
+        }
+    }
+    // Long runs of dependent blocks -- a stream written by the reference's compressor is ONE such run -- in pieces of
+    // consecutive blocks, every piece decoded twice with two stand-ins for its missing dictionary; what differs is what is
+    // not final yet, and that decays to nothing within a piece (kernels.hip, "TWIN DECODE").  One byte of scratch per
+    // output byte of a segment (<= 2 GiB).  A piece is a serial chain of block decodes (0.45 ms each), so the path pays
+    // where the pieces fill the chip anyway: spans of 12 288 blocks and more (measured on text, 64 KiB blocks: 16 384
+    // blocks 12.5 against 16.2 ms for the pointer pass; 4 096 blocks would take 10 against 4.5 ms).
+    // MI355LZ4_LINKED_TWIN: 0 = never, 1 = whenever it applies (the tests); MI355LZ4_LINKED_TWIN_PIECE: blocks per
+    // piece (default 16: with 8 the taint reaches a piece's last block often enough to chain the pieces' second halves).
+    {
+        const char *envTwin = getenv("MI355LZ4_LINKED_TWIN"), *envPiece = getenv("MI355LZ4_LINKED_TWIN_PIECE");
+        const bool plain = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS");
+        const int span0 = last - first + 1;
+        const bool useTwin = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
+                             (envTwin ? atoi(envTwin) != 0 : (plain && span0 >= 12288));
+        if (useTwin) {
+            const uint64_t stride = (((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u) * 65536u;
+            const int piece = (envPiece && atoi(envPiece) > 0) ? atoi(envPiece) : 16;
+            // a piece's wave polls for the piece in front for up to ~20 ms (s_sleep 64 = 4096 cycles a poll) as long as every
+            // piece of the launch has a wave slot of its own (256 CUs x 8 waves at least): no wave waits for one not yet started
+            const char *envSpin = getenv("MI355LZ4_LINKED_TWIN_SPIN");
+            a.twinSpin = envSpin ? atoi(envSpin) : 10000;
+            int segBlocks = (int)(((uint64_t)1 << 31) / stride);
+            segBlocks = segBlocks / piece * piece;
+            if (segBlocks < piece) segBlocks = piece;
+            if (segBlocks > span0) segBlocks = (span0 + piece - 1) / piece * piece;
+            const size_t nPiecesMax = (size_t)segBlocks / piece + 1;
+            const size_t metaBytes = 131072 + (size_t)segBlocks * 8 + (2 + nPiecesMax) * 4 + 64;
+            bool done = false;
+            if (dev_reserve(c->ptrBuf, (size_t)segBlocks * stride) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0) {
+                uint8_t *meta = (uint8_t *)c->tolMeta.p;
+                a.seamPages = meta; a.twin = (uint8_t *)c->ptrBuf.p; a.twinStride = stride; a.twinPiece = piece;
+                a.twinRes = (int32_t *)(meta + 131072); a.twinTaint = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 4);
+                a.twinCtl = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 8);
+                HIP_TRY(hipMemsetAsync(meta, 0x00, 65536, c->stream));
+                HIP_TRY(hipMemsetAsync(meta + 65536, 0xff, 65536, c->stream));
+                done = true;
+                for (int s0 = first; s0 <= last && done; s0 += segBlocks) {
+                    a.segFirst = s0; a.segEnd = (s0 + segBlocks < last + 1) ? s0 + segBlocks : last + 1;
+                    if ((a.segEnd - a.segFirst + piece - 1) / piece > 2048) a.twinSpin = 0;
+                    HIP_TRY(hipMemsetAsync(a.twinCtl, 0, 8, c->stream));
+                    launch_twin_decode(a, c->stream);
+                    bool segDone = false;
+                    for (int round = 0; round < 64 && !segDone; round++) {
+                        launch_twin_fix(a, c->stream);
+                        HIP_TRY(hipMemcpyAsync(stat, a.twinCtl, 8, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(hipStreamSynchronize(c->stream));
+                        if (stat[1] != 0) break;                 // a block failed with its true dictionary
+                        segDone = stat[0] == 0;
+                    }
+                    done = segDone;
+                }
+            }
+            (void)hipGetLastError();
+            if (done) { link_scratch_release(c); return check_launch("decode launch"); }
+            // Not finished this way (a broken block, pieces that never become final, no scratch): what is final is final; the
+            // blocks that still carry the first pass's codec error go through the pointer / serial pass below
+            a.twin = nullptr; a.seamPages = nullptr; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
+            a.segFirst = 0; a.segEnd = nBlocks;
+            HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
+            HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
+            launch_link_stat(a, c->stream);
+            HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
+            first = (int)stat[1]; last = (int)stat[2];
+            if (first < 0 || last >= nBlocks || first > last) {
+                link_scratch_release(c);
+                return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
+            }
         }
     }
     // Lists of deferred matches for up to POOL_BLOCKS dependent blocks at a time (64 KiB each: one byte per output
@@ -1613,7 +1684,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.streamFirst = nullptr; a.nStreams = 0; a.lookBack = 0;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
-    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.twin = nullptr; a.twinStride = 0; a.seamPages = nullptr; a.twinPiece = 0; a.twinSpin = 0; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
     if (s->dictLen) {
         // the exact decoder with the dictionary in force, at once (a block that does not reach back decodes the same)
         if (hipMemcpyAsync(resDev, (const uint8_t *)s->inDev.p + 16, 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;

@@ -52,6 +52,15 @@ struct DecodeArgs {
     // runList[1..] = first block of each run, at most runCap of them; null: the launch covers one run that starts at segFirst
     int32_t *runList;
     int runCap;
+    // long linked streams, twin decode (kernels.hip, k_twin_*): pieces of twinPiece consecutive blocks of [segFirst, segEnd)
+    uint8_t *twin;                // the second decode's output: block f at twin + (f - segFirst) * twinStride
+    uint64_t twinStride;
+    const uint8_t *seamPages;     // 2 x 64 KiB: all 0x00, all 0xFF -- the two stand-ins for a piece's missing dictionary
+    int twinPiece;                // blocks per piece
+    int twinSpin;                 // k_twin_fix: how many times a piece polls for the piece in front of it before it leaves itself to the next launch
+    int32_t *twinRes;             // per block of the segment: the first pass's result with the stand-in (sizes do not depend on it)
+    uint32_t *twinTaint;          // per block of the segment: bytes that differ between the two decodes (0: the block is final)
+    uint32_t *twinCtl;            // [0] pieces not final yet, [1] a block failed with its true dictionary (caller falls back), [2 + p] piece p final
     // experiment builds only (MI355LZ4_EXPERIMENTS; decode_par.hpp, LIST): block blk's token list lives at tokList +
     // blockOff[blk] / 2 (a sequence is at least three compressed bytes), tokCnt[blk] entries; both null without the list pass
     uint8_t *tokList;
@@ -100,6 +109,9 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fet
 void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: the fetch of block a.onlyBlk alone; PtrCtl::lastOpen tells whether it is complete
 size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
+void launch_link_stat(const DecodeArgs &a, hipStream_t s);       // linkStat from result[] (the decode launchers call it themselves)
+void launch_twin_decode(const DecodeArgs &a, hipStream_t s);     // long linked stream: both decodes of every piece + the comparison
+void launch_twin_fix(const DecodeArgs &a, hipStream_t s);        // ... one round of pieces whose dictionary has become final
 void launch_linked_runs(const DecodeArgs &a, hipStream_t s);      // one stream, short runs of dependent blocks: one wave per run, exact decoder with dictionary
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();

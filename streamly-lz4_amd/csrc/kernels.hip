@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_link_stat(DecodeArgs a)
         atomicMax(&a.linkStat[4], sh[3]);          // the largest such block sizes the second pass's scratch
     }
 }
-static void launch_link_stat(const DecodeArgs &a, hipStream_t s)
+void launch_link_stat(const DecodeArgs &a, hipStream_t s)
 {
     if (a.linkStat && a.nBlocks > 0)
         hipLaunchKernelGGL(k_link_stat, dim3((unsigned)((a.nBlocks + 1023) / 1024)), dim3(1024), 0, s, a);
@@ -702,6 +702,208 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
         }
         if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long linked streams: TWIN DECODE (round 5).  In a stream written by the reference's compressor every block needs the
+// block before it, but not much of it: on text a third of a block's bytes derive -- through chains of matches -- from
+// the previous block, 5 % from the one before that, 1 % from the third, and after about eight blocks nothing is left
+// (scripts/tol_taint_sim.py; byte-exact -- tracked per match, as the tolerant pass has to, the dependent share stays at
+// 76 % in every block, which is why that pass hands practically the whole stream to the pointer machinery).  So the
+// stream is cut into PIECES of consecutive blocks and one wavefront decodes a piece in order with the ordinary
+// lane-parallel decoder, every block with the block before it as its dictionary -- only the piece's first block lacks
+// its own.  It gets a stand-in, and the piece is decoded TWICE (two waves, side by side): once with 64 KiB of 0x00 in
+// the dictionary's place and once with 64 KiB of 0xFF.  A byte that derives from the missing dictionary, by whatever
+// chain, is a copy of one of its bytes and comes out 0x00 in one decode and 0xFF in the other; every other byte is the
+// same in both.  Comparing the two outputs therefore marks, exactly, the bytes that are not final -- no taint logic in
+// the decoder, no lists, no pointers; one byte of scratch per output byte.  A block's SIZE and result code depend on
+// its tokens only, so they are known after this pass.
+//   Then the pieces are finished front to back where it matters: a piece whose predecessor's last block is final
+// (no differing byte: the normal case with eight blocks per piece) re-decodes its leading blocks with the true
+// dictionary until it reaches a block without a differing byte; pieces whose predecessor is not final yet wait for the
+// next round (k_twin_fix is launched until a counter says that no piece is left).  Anything unusual -- a block that
+// fails with its true dictionary, too many rounds -- leaves the remaining blocks' results as the first pass had them and
+// the caller continues with the pointer pass, which treats what is final as final.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool twin_true_dict(const DecodeArgs &a, int b0)
+{
+    // the block in front of the piece decoded in the first (standalone) pass: its output is the piece's real dictionary
+    return b0 == a.segFirst ? true : uni(a.result[b0 - 1]) > 0;
+}
+__device__ __forceinline__ void twin_dict_before(const DecodeArgs &a, int b0, const uint8_t *&dict, uint32_t &dictLen)
+{
+    dict = nullptr; dictLen = 0;
+    if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
+    for (int j = b0 - 1; j >= -a.lookBack; j--) {
+        const int rj = uni(a.result[j]);
+        if (rj > 0) { dict = a.out + a.outOff[j]; dictLen = (uint32_t)rj; break; }
+    }
+}
+
+// grid: 2 waves per piece (blockIdx & 1: 0 = the decode into the caller's buffer, stand-in 0x00; 1 = the twin, 0xFF)
+__global__ PAR_OCC void k_twin_decode(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int which = (int)(blockIdx.x & 1u), piece = (int)(blockIdx.x >> 1);
+    const int b0 = a.segFirst + piece * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
+    if (b0 >= b1) return;
+    const bool trueDict = twin_true_dict(a, b0);
+    if (trueDict && which) return;                               // nothing is missing: one decode, and it is final
+    const uint8_t *dict; uint32_t dictLen;
+    if (trueDict) twin_dict_before(a, b0, dict, dictLen);
+    else { dict = a.seamPages + (which ? 65536 : 0); dictLen = 65536u; }
+    for (int f = b0; f < b1; f++) {
+        const int r0 = uni(a.result[f]);                         // the standalone pass's result: nobody writes it in this launch
+        uint8_t *real = a.out + a.outOff[f];
+        if (r0 > 0) { dict = real; dictLen = (uint32_t)r0; if (!which && lane_id() == 0) a.twinRes[f - a.segFirst] = r0; continue; }
+        int r = r0;
+        uint8_t *dst = which ? a.twin + (uint64_t)(f - a.segFirst) * a.twinStride : real;
+        if (is_codec_error(r0) && dictLen > 0) {
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, f, data, compLen, cap);
+            if (r == 0 && (uint64_t)cap > a.twinStride) r = -1;  // (cannot happen: the stride is the largest capacity)
+            if (r == 0)
+                r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
+            r = uni(r);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+        if (!which && lane_id() == 0) a.twinRes[f - a.segFirst] = r;
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }         // :2331-2333, :2353-2355: an empty or failed block leaves the dictionary
+    }
+}
+
+// one workgroup per block: how many bytes differ between the two decodes
+__global__ __launch_bounds__(256) void k_twin_compare(DecodeArgs a)
+{
+    const int f = a.segFirst + (int)blockIdx.x;
+    const int b0 = a.segFirst + ((f - a.segFirst) / a.twinPiece) * a.twinPiece;
+    const int r0 = a.result[f], r = a.twinRes[f - a.segFirst];
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    if (!twin_true_dict(a, b0) && r0 <= 0 && r > 0) {
+        const uint8_t *x = a.out + a.outOff[f], *y = a.twin + (uint64_t)(f - a.segFirst) * a.twinStride;
+        for (int i = (int)threadIdx.x * 16; i < r; i += 256 * 16) {
+            if (i + 16 <= r && (((uintptr_t)(x + i)) & 15u) == 0) {
+                const uint4 u = *(const uint4 *)(x + i), v = *(const uint4 *)(y + i);
+                mine += (uint32_t)((u.x != v.x) + (u.y != v.y) + (u.z != v.z) + (u.w != v.w));
+            } else {
+                for (int k = i; k < min(i + 16, r); k++) mine += (uint32_t)(x[k] != y[k]);
+            }
+        }
+    }
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) a.twinTaint[f - a.segFirst] = cnt;
+}
+
+// pieces left to finish = those decoded with a stand-in; the others are final as they are
+__global__ __launch_bounds__(256) void k_twin_begin(DecodeArgs a)
+{
+    const int nPieces = (a.segEnd - a.segFirst + a.twinPiece - 1) / a.twinPiece;
+    const int p = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (p >= nPieces) return;
+    const int b0 = a.segFirst + p * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
+    if (twin_true_dict(a, b0)) {
+        a.twinCtl[2 + p] = 2u;                                   // final; its results are published by k_twin_publish
+    } else {
+        a.twinCtl[2 + p] = 0u;
+        atomicAdd(&a.twinCtl[0], 1u);
+    }
+    (void)b1;
+}
+// (a launch of its own: k_twin_begin reads result[b0 - 1] of every piece, this one overwrites results)
+__global__ __launch_bounds__(256) void k_twin_publish(DecodeArgs a)
+{
+    const int f = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
+    if (f >= a.segEnd) return;
+    const int p = (f - a.segFirst) / a.twinPiece;
+    if (a.twinCtl[2 + p] == 2u) {
+        const int r = a.twinRes[f - a.segFirst];
+        if (a.result[f] <= 0) a.result[f] = r;
+        if (r < 0 && is_codec_error(r)) atomicOr(&a.twinCtl[1], 1u);      // failed with its true dictionary: the caller's other path reports it
+    }
+}
+
+// one wave per piece: finish it if the piece in front is final
+__global__ PAR_OCC void k_twin_fix(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int p = (int)blockIdx.x;
+    const int b0 = a.segFirst + p * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
+    if (b0 >= b1 || uni((int)a.twinCtl[2 + p]) != 0) return;                          // final already
+    // The piece's dictionary is the block in front of it.  That block is final when its piece is, or -- the normal case --
+    // when the first pass already left no differing byte in it: the taint has died out before the piece's end.
+    const uint8_t *dict = nullptr; uint32_t dictLen = 0;
+    {
+        const int j = b0 - 1 - a.segFirst;                       // (p > 0 here: piece 0 has its true dictionary and is never pending)
+        const int rj = uni(a.twinRes[j]);
+        const bool clean = rj > 0 && uni(a.result[b0 - 1]) <= 0 && uni((int)a.twinTaint[j]) == 0;
+        bool prevFinal = uni((int)__hip_atomic_load(&a.twinCtl[2 + p - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+        // Not ready: the piece in front is being finished by a wave of this launch (they are dispatched in order: it is
+        // resident whenever this one is).  Wait for it a bounded while -- a wait that gives up is a piece left for the next
+        // launch, never a wave that cannot end.
+        for (int spin = 0; !clean && !prevFinal && spin < a.twinSpin; spin++) {
+            __builtin_amdgcn_s_sleep(64);
+            prevFinal = uni((int)__hip_atomic_load(&a.twinCtl[2 + p - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+        }
+        if (!clean && !prevFinal) return;                        // next round
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        if (clean && !prevFinal) { dict = a.out + a.outOff[b0 - 1]; dictLen = (uint32_t)rj; }   // (its result is not published yet)
+        else twin_dict_before(a, b0, dict, dictLen);
+    }
+    bool redo = true;                                            // blocks with differing bytes form a prefix of the piece
+    for (int f = b0; f < b1; f++) {
+        const int r0 = uni(a.result[f]);
+        uint8_t *dst = a.out + a.outOff[f];
+        int r = r0 > 0 ? r0 : uni(a.twinRes[f - a.segFirst]);
+        if (r0 <= 0) {
+            // (only a block that was decoded says anything about the bytes behind it: an empty or rejected block leaves the
+            // dictionary where it was)
+            if (redo && is_codec_error(r0) && r > 0 && uni((int)a.twinTaint[f - a.segFirst]) == 0) redo = false;
+            if (redo && is_codec_error(r0) && dictLen > 0) {
+                const uint8_t *data = nullptr;
+                int compLen = 0, cap = 0;
+                r = read_block_header(a, f, data, compLen, cap);
+                if (r == 0)
+                    r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
+                r = uni(r);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            }
+            if (r < 0 && is_codec_error(r)) {
+                // fails with its true dictionary: the stream is broken here.  The block keeps the standalone pass's result and
+                // the caller's pointer / serial path produces the reference's code and what follows from it (:2331, :2353)
+                if (lane_id() == 0) atomicOr(&a.twinCtl[1], 1u);
+                return;
+            }
+            if (lane_id() == 0) a.result[f] = r;
+        }
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    if (lane_id() == 0) {
+        __hip_atomic_store(&a.twinCtl[2 + p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicSub(&a.twinCtl[0], 1u);
+    }
+}
+
+void launch_twin_decode(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
+    const int nPieces = (n + a.twinPiece - 1) / a.twinPiece;
+    hipLaunchKernelGGL(k_twin_decode, dim3((unsigned)nPieces * 2u), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_twin_compare, dim3((unsigned)n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_twin_begin, dim3((unsigned)((nPieces + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_twin_publish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_twin_fix(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_twin_fix, dim3((unsigned)((n + a.twinPiece - 1) / a.twinPiece)), dim3(64), 0, s, a);
 }
 
 void launch_linked_runs(const DecodeArgs &a, hipStream_t s)

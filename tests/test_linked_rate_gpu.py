@@ -194,3 +194,49 @@ def test_single_linked_stream_host_api_rate(engine, slz4, oracle, linked):
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
+
+
+def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeypatch):
+    """ONE reference-written linked stream long enough (12 288 blocks of 64 KiB and more) that the default path is the
+    twin decode (pieces of 16 blocks decoded with two stand-ins for the missing dictionary, kernels.hip): its output must
+    be the input, and the same bytes as the pointer pass's (MI355LZ4_LINKED_TWIN=0).  Rates go to linked_rate.json."""
+    import torch
+    dev = torch.device("cuda:0")
+    bl, nb, base = 65536, 12288 + 40, 1024                   # (a ragged last piece)
+    data = oracle.gen("text", base, bl, first_block=555).tobytes()
+    data = (data * ((nb + base - 1) // base))[: nb * bl]
+    fr = oracle.frame_compress(data, bl, 1, 8, True)
+    offs = np.zeros(nb + 1, dtype=np.int64)
+    pos = 0
+    for i in range(nb):
+        offs[i] = pos
+        pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+    offs[nb] = pos
+    buf = torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).to(dev)
+    off = torch.from_numpy(offs).to(dev)
+    ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+    res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    e0, e1 = slz4.Event(), slz4.Event()
+    rates = {}
+    for label, env in (("twin (default)", None), ("pointer pass", "0")):
+        if env is None:
+            monkeypatch.delenv("MI355LZ4_LINKED_TWIN", raising=False)
+        else:
+            monkeypatch.setenv("MI355LZ4_LINKED_TWIN", env)
+        out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
+        best = 1e9
+        for _ in range(2):
+            engine.record(e0)
+            engine.decompress_batch_device(buf, len(fr), off, nb, out, ooff, res, linked=True)
+            engine.record(e1)
+            engine.synchronize()
+            best = min(best, engine.elapsed_ms(e0, e1))
+        assert bool((res == bl).all().item()) and torch.equal(out, src), label
+        rates[label] = round(nb * bl / best / 1e6, 2)
+        del out
+    rec = {"streams": 1, "blocks": nb, "block_len": bl, "data": "text, reference-linked, one stream", "GBps_uncompressed": rates}
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)
+    assert rates["twin (default)"] > rates["pointer pass"]

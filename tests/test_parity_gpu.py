@@ -657,6 +657,12 @@ LINKED_VARIANTS = {
     # no host wait: the second pass is enqueued over all blocks, gated on the device (mi355lz4_set_linked_async)
     "async": {"MI355LZ4_LINKED_ASYNC": "4194304"},
     "async_segments_of_3": {"MI355LZ4_LINKED_ASYNC": "4194304", "MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
+    # twin decode (round 5; by default only for spans of 12 288 blocks and more): pieces of 16, and short pieces that chain --
+    # with and without the wait inside a launch -- and run out of rounds, which hands the rest to the pointer pass
+    "twin": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_RUNS": "0"},
+    "twin_pieces_of_2": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": "2", "MI355LZ4_LINKED_RUNS": "0"},
+    "twin_pieces_of_3_no_wait": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": "3", "MI355LZ4_LINKED_TWIN_SPIN": "0",
+                                 "MI355LZ4_LINKED_RUNS": "0"},
 }
 
 
