@@ -740,8 +740,14 @@ __device__ __forceinline__ void twin_dict_before(const DecodeArgs &a, int b0, co
     }
 }
 
+// (a piece is a serial chain of block decodes: what counts is one wave's speed, and the dictionary form of the decoder
+// spills at the 96 registers that five waves per SIMD allow -- these kernels take 128)
+#ifndef TWIN_WAVES
+#define TWIN_WAVES 4
+#endif
+#define TWIN_OCC __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TWIN_WAVES, TWIN_WAVES)))
 // grid: 2 waves per piece (blockIdx & 1: 0 = the decode into the caller's buffer, stand-in 0x00; 1 = the twin, 0xFF)
-__global__ PAR_OCC void k_twin_decode(DecodeArgs a)
+__global__ TWIN_OCC void k_twin_decode(DecodeArgs a)
 {
     __shared__ ParLds lds;
     const int which = (int)(blockIdx.x & 1u), piece = (int)(blockIdx.x >> 1);
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(256) void k_twin_publish(DecodeArgs a)
 }
 
 // one wave per piece: finish it if the piece in front is final
-__global__ PAR_OCC void k_twin_fix(DecodeArgs a)
+__global__ TWIN_OCC void k_twin_fix(DecodeArgs a)
 {
     __shared__ ParLds lds;
     const int p = (int)blockIdx.x;
