@@ -18,7 +18,10 @@
 
 namespace lz4dev {
 
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// The lane's number within its wavefront, from the hardware's lane mask count rather than from threadIdx: a function that
+// never reads the work-item id does not need it handed over in v31 at a call, and a kernel that never reads it does not
+// keep (or spill) the register it arrives in.  (One-dimensional workgroups: a wave is 64 consecutive threads.)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
