@@ -14,6 +14,8 @@ bash scripts/profile_bench.sh text --workload text > "$E/profile_text.log" 2>&1
 for k in lzsynth text; do bash scripts/pmc_encode.sh $k > "$E/encode_${k}_pmc_instmix.txt" 2>&1; done
 for k in lzsynth text; do bash scripts/pmc_decode.sh $k > "$E/decode_${k}_pmc_instmix.txt" 2>&1; done
 python3 bench.py --workload roundtrip --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_roundtrip.json" 2> "$E/bench_roundtrip.err"
+# BASELINE config 4's per-GPU share (64 GiB / 8): 131 072 blocks, one call each way
+python3 bench.py --workload roundtrip --blocks 131072 --steps 5 --warmup 1 --no-cpu-baseline --no-host-api > "$E/bench_roundtrip_8GiB.json" 2> "$E/bench_roundtrip_8GiB.err"
 python3 bench.py --workload random256k --steps 10 --warmup 2 --no-cpu-baseline --no-host-api > "$E/bench_random256k.json" 2> "$E/bench_random256k.err"
 python3 bench.py --workload text --steps 20 --warmup 2 --linked-compress --no-cpu-baseline > "$E/bench_text_linked_compress.json" 2> "$E/bench_text_linked_compress.err"
 python3 bench.py --steps 20 --warmup 2 --linked --no-cpu-baseline --no-host-api --no-extra > "$E/bench_linked1.json" 2> "$E/bench_linked1.err"
@@ -28,6 +30,8 @@ for N in 2 3; do
       bench.py --gpus $N --steps 5 --warmup 1 --workload text --one-stream --blocks 2048 2>/dev/null | grep '^{' >> "$E/bench_one_stream_rehearsal.jsonl"
 done
 ( cd /tmp && export TMPDIR=/tmp && rm -rf "$E/linked_prof" && rocprofv3 --kernel-trace --stats --output-format csv -d "$E/linked_prof" -- python3 "$R/scripts/prof_linked.py" 4096 5 > "$E/linked_prof.log" 2>&1; cp "$E"/linked_prof/*/*kernel_stats.csv "$E/linked_single_stream_kernel_stats.csv" 2>/dev/null )
+# one reference-written linked text stream of 1, 2 and 4 GiB: pointer pass against twin decode
+for nb in 16384 32768 65536; do TWIN_PIECES=12,16 python3 scripts/linked_twin_time.py text $nb 2>/dev/null | grep -v amdgpu; done > "$E/linked_twin_decode.txt"
 python3 scripts/linked_async_cost.py 2>/dev/null | grep blocks > "$E/linked_async_cost.txt"
 python3 scripts/realtext_ratio.py 2>/dev/null | grep input > "$E/realtext_ratio.txt"
 python3 scripts/size_vs_ref.py 2>/dev/null | grep segs > "$E/size_vs_reference.txt"

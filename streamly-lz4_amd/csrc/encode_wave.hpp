@@ -167,9 +167,22 @@ __device__ __forceinline__ int enc_writelane(int v, int x, int k) { return enc_l
 // ballot of a predicate (HIP's __ballot takes an int: the predicate would travel through a register as 0 / 1 and a compare)
 __device__ __forceinline__ uint64_t enc_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
+// The shape of the groups that measure the run heads' matches (encode_wave.hpp, "dense window"): GL lanes of 16 bytes each
+// per head -- 4: the 8 bytes before the head and the 56 after, 16 heads a round; 2: 8 + 24, 32 heads a round.
+template <int GLANES> struct EncGroups {
+    static constexpr uint32_t GL = GLANES, GR = 64u / GLANES;          // lanes per group, groups per round
+    static constexpr int GSH = (GLANES == 4) ? 4 : 3;                  // log2 of a group's byte address step (4 bytes a lane)
+};
+
 // minimum over each group of four lanes, in all four: two v_min_u32 with a quad_perm DPP operand.  (Written out: the
 // compiler keeps a copy and a v_mov_dpp per step otherwise.  The s_nop is the two wait states a DPP read of a
 // freshly written register needs; the hazard pass does not look into asm.)
+__device__ __forceinline__ uint32_t enc_pair_min(uint32_t g)      // ... over each pair of lanes (groups of two: ENC_GROUP_LANES 2)
+{
+    uint32_t r;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(g));
+    return r;
+}
 __device__ __forceinline__ uint32_t enc_quad_min(uint32_t g)
 {
     uint32_t r;
@@ -483,12 +496,23 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         const LZ4_GLOBAL uint8_t *gsrc = as_global(src);
         auto load16 = [&](uint32_t off) -> dev_v4 { return *(const LZ4_GLOBAL dev_v4u *)(gsrc + off); };
         const bool pipeFits = n < (1 << 24);           // a group's candidate travels in 25 bits, an end in 24
+#ifndef ENC_GROUPS
+#define ENC_GROUPS 0          // 0: adaptive; 2 / 4: one shape (measurements)
+#endif
+        // the groups' shape (see shape_update below): windows and long matches counted, extensions made since the count was
+        // last looked at
+        int shapeWin = 0, shapeLong = 0, shapeExt = 0;
+        bool shapeCounting = ENC_GROUPS == 0;
         // lane constants of the groups: lane j of a group holds bytes [16 j - 8, 16 j + 8) relative to the head
-        const uint32_t j4 = (uint32_t)lane & 3u;
+        // (two shapes, ENC_GROUPS in kernels: the wave switches between them with what the block's matches look like)
         // bit offsets of a lane's four words; a group's lane 0 holds the 8 bytes BEFORE the head in its first two: ~0 keeps
         // them out of the minimum
-        const uint32_t gc0 = j4 ? j4 << 7 : 0xffffffffu, gc1 = j4 ? (j4 << 7) | 32u : 0xffffffffu, gc2 = (j4 << 7) | 64u, gc3 = (j4 << 7) | 96u;
-        const uint32_t j16 = j4 << 4;
+        struct GC { uint32_t c0, c1, c2, c3, j16; };
+        auto group_consts = [&](const uint32_t j) -> GC {
+            return GC{j ? j << 7 : 0xffffffffu, j ? (j << 7) | 32u : 0xffffffffu, (j << 7) | 64u, (j << 7) | 96u, j << 4};
+        };
+        const GC gc4 = group_consts((uint32_t)lane & 3u);
+        // (groups of two make theirs where they are used: five registers that the groups of four's steady state does not carry)
         const uint32_t lanePay = (uint32_t)lane << 25;        // a head's message to its group: lane | candidate - 8
 
         // First difference of a group's 64 + 64 bytes, in every lane of the group:
@@ -496,10 +520,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         //   bits 8..11 equal bytes just before the head (0..8), meaningful in the group's lane 0 only
         // v_ffbl_b32 gives 0..31 or ~0: "or"-ing the word's bit offset in keeps ~0 for equal words, so the minimum over
         // the group is the first differing bit of its 512 (or ~0).
-        auto group_len = [&](const dev_v4 &a, const dev_v4 &b) -> uint32_t {
+        auto group_len = [&](auto G, const dev_v4 &a, const dev_v4 &b) -> uint32_t {
+            constexpr uint32_t GL = decltype(G)::GL;
+            const GC gc = (GL == 4u) ? gc4 : group_consts((uint32_t)lane & 1u);
             const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-            uint32_t g = min(min(ffbl32(x0) | gc0, ffbl32(x1) | gc1), ffbl32(x2) | gc2);
-            g = enc_quad_min(min(min(g, ffbl32(x3) | gc3), 512u));             // (512: nothing differs within the horizon)
+            uint32_t g = min(min(ffbl32(x0) | gc.c0, ffbl32(x1) | gc.c1), ffbl32(x2) | gc.c2);
+            g = min(min(g, ffbl32(x3) | gc.c3), GL * 128u);                     // (the group's bits: nothing differs within the horizon)
+            g = (GL == 4u) ? enc_quad_min(g) : enc_pair_min(g);
             const uint32_t t = g >> 3;
             const uint32_t back = min(min(ffbh32(x1), ffbh32(x0) | 32u) >> 3, 8u);
             return t | (back << 8);
@@ -543,6 +570,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             uint32_t m0;                                // hit lanes: match length from this lane on (0..56; 63 once extended)
             int endv;                                   // hit lanes: end of that match
             uint64_t hitm, capm;
+            uint64_t longm;                             // hit lanes whose run is at least 24 bytes long from its head: groups of two would have to extend them
         };
         auto lw_probe = [&](LW &W, const uint32_t pos, const uint64_t v8, const bool insertNow) {
             const uint32_t hx = hash5x(v8);
@@ -558,7 +586,8 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         };
-        auto lw_heads = [&](LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t offBefore, const uint64_t okBefore) {
+        auto lw_heads = [&](auto G, LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t offBefore, const uint64_t okBefore) {
+            constexpr uint32_t GR = decltype(G)::GR; constexpr int GSH = decltype(G)::GSH;
             // (predicates are kept as scalar masks -- one compare each, combined by the scalar unit -- and turned back
             // into lane predicates where a select needs them)
             uint64_t okm = enc_ballot((W.tagWord & W.tmask) == W.tbits);
@@ -579,35 +608,39 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             W.off = pos8 - c8;
             const uint32_t offLeft = (uint32_t)__builtin_amdgcn_update_dpp((int)offBefore, (int)W.off, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             W.headm = okm & ~(enc_ballot(W.off == offLeft) & ((okm << 1) | okBefore));
-            W.twoRounds = __builtin_popcountll(W.headm) > 16;
-            W.rank4 = enc_mbcnt(W.headm) << 4;                     // byte address of lane 4 * rank
+            W.twoRounds = __builtin_popcountll(W.headm) > (int)GR;
+            W.rank4 = enc_mbcnt(W.headm) << GSH;                   // byte address of lane GL * rank
             // heads 0..15, one per group of four lanes (lane 1 takes what the others send)
             const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot(W.rank4 < 256u)) ? (int)W.rank4 : 4;
             W.gi0 = (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | c8));
         };
         // a group's requests.  A group without a head decodes lane 0, candidate 8: bytes that are there (p0w >= 8)
-        auto lw_fetch = [&](const uint32_t giRaw, const int p0w, dev_v4 &a, dev_v4 &b) {
-            const uint32_t gi = (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0x00 /* quad_perm 0,0,0,0 */, 0xf, 0xf, true);
+        auto lw_fetch = [&](auto G, const uint32_t giRaw, const int p0w, dev_v4 &a, dev_v4 &b) {
+            constexpr uint32_t GL = decltype(G)::GL;
+            const uint32_t j16 = (GL == 4u) ? gc4.j16 : ((uint32_t)lane & 1u) << 4;
+            const uint32_t gi = (GL == 4u) ? (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0x00 /* quad_perm 0,0,0,0 */, 0xf, 0xf, true)
+                                           : (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0xa0 /* quad_perm 0,0,2,2 */, 0xf, 0xf, true);
             a = load16((uint32_t)(p0w - 8) + (gi >> 25) + j16);
             b = load16((gi & 0x1ffffffu) + j16);
         };
-        auto lw_loads = [&](LW &W, const int p0w) {
-            lw_fetch(W.gi0, p0w, W.a0, W.b0);
+        auto lw_loads = [&](auto G, LW &W, const int p0w) {
+            lw_fetch(G, W.gi0, p0w, W.a0, W.b0);
             if (W.twoRounds) {                                     // heads 16..31 (one window in four has them)
                 const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot((W.rank4 >> 8) == 1u)) ? (int)(W.rank4 & 255u) : 4;
-                lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, W.a1, W.b1);
+                lw_fetch(G, (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, W.a1, W.b1);
             }
         };
         // heads beyond the 32nd of a window: one more round of groups at a time, requested and waited for here.
         // Generated text has 14-17 heads per window; source code 25-27, and leaving the heads past the 32nd without a
         // match cost 2 % of its ratio (oracle/sim_encode2.c, headcap32).
-        auto more_rounds = [&](const LW &W, const int p0w, uint32_t r) -> uint32_t {
+        auto more_rounds = [&](auto G, const LW &W, const int p0w, uint32_t r) -> uint32_t {
+            constexpr uint32_t GR = decltype(G)::GR;
             const int nH = (int)__builtin_popcountll(W.headm);
-            for (int rr = 2; rr * 16 < nH; rr++) {
+            for (int rr = 2; rr * (int)GR < nH; rr++) {
                 const int dest = __builtin_amdgcn_inverse_ballot_w64(W.headm & enc_ballot((int)(W.rank4 >> 8) == rr)) ? (int)(W.rank4 & 255u) : 4;
                 dev_v4 a, b;
-                lw_fetch((uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, a, b);
-                const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(a, b));
+                lw_fetch(G, (uint32_t)__builtin_amdgcn_ds_permute(dest, (int)(lanePay | W.c8)), p0w, a, b);
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(G, a, b));
                 if ((int)(W.rank4 >> 8) == rr) r = r2;
             }
             return r;
@@ -615,19 +648,21 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // lengths, in two steps so that a pair's two cross-lane reads travel together.  lw_measure: each head lane fetches its
         // group's result (W.r).  lw_hits: headConst = (idx + 1) << 16 | idx, idx8 = idx + 8; hvBefore = the scan value of the
         // last lane of the window before (its run may go on into this one)
-        auto lw_measure = [&](LW &W, const int p0w) {
-            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a0, W.b0));
+        auto lw_measure = [&](auto G, LW &W, const int p0w) {
+            constexpr uint32_t GR = decltype(G)::GR;
+            uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(G, W.a0, W.b0));
             if (W.twoRounds) {
-                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(W.a1, W.b1));
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(W.rank4 & 255u), (int)group_len(G, W.a1, W.b1));
                 if (W.rank4 >= 256u) r = r1;
             }
 #ifdef ENC_STATS
             est[7] += (unsigned)__builtin_popcountll(W.headm);
 #endif
-            if (__builtin_popcountll(W.headm) > 32) r = more_rounds(W, p0w, r);
+            if (__builtin_popcountll(W.headm) > 2 * (int)GR) r = more_rounds(G, W, p0w, r);
             W.r = r;
         };
-        auto lw_hits = [&](LW &W, const int p0w, const uint32_t headConst, const uint32_t idx8, const uint32_t hvBefore) {
+        auto lw_hits = [&](auto G, LW &W, const int p0w, const uint32_t headConst, const uint32_t idx8, const uint32_t hvBefore) {
+            constexpr uint32_t GL = decltype(G)::GL;
             // every lane learns its run's head with a max-scan: head lanes put their index above their result, the others 0,
             // and the largest value at or below a lane belongs to the nearest head below it.  The low byte is t + head idx,
             // so that a lane's own length is one subtraction: (t - 8) - (idx - head idx).
@@ -638,7 +673,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             W.endv = (int)E + (p0w - 8 - (int)(idx8 - 8u - (uint32_t)lane));        // position + m0 (the bracket is wave-uniform)
             W.hitm = W.candm & enc_ballot(m0 >= LZ4_MINMATCH);
             // ... and whether its run reached the horizon: t = 64
-            W.capm = W.hitm & enc_ballot((W.hv & 0xffu) - (W.hv >> 16) == 63u);
+            const uint32_t tm1 = (W.hv & 0xffu) - (W.hv >> 16);    // t - 1
+            W.capm = W.hitm & enc_ballot(tm1 == GL * 16u - 1u);
+            W.longm = 0;
+            if (GL == 4u && shapeCounting) W.longm = W.hitm & enc_ballot(tm1 >= 31u);
         };
         // greedy selection in this window, continuing from pEnd (the end of the last selected match so far): scalar, one
         // v_readlane per match taken
@@ -652,6 +690,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 enc_select_run(hm, selm, pEnd, k, W.capm, W.endv, p0w);
                 if (k < 0) break;
                 // lane k's run reached the horizon: the whole wave counts on
+                shapeExt++;
                 int endk = __builtin_amdgcn_readlane(W.endv, k);
                 const int ce = __builtin_amdgcn_readlane((int)W.c8, k) + 8 + (endk - (p0w + k));
                 endk += extend_long(endk, ce);
@@ -711,21 +750,41 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         };
         const uint32_t hc0 = (((uint32_t)lane + 1u) << 16) | (uint32_t)lane, hc1 = hc0 + ((64u << 16) | 64u);
 
+        // Which shape the groups have is the wave's choice, block by block: groups of four measure 56 bytes behind a head in
+        // one go, groups of two 24 -- half the requests, 32 heads a round (no second round), and a match that reaches the
+        // 24 is extended by the whole wave.  Measured with one shape for everything: text 165 (four) against 187 GB/s (two),
+        // lzsynth -- matches of 20 bytes on average -- 201 against 153.  A block starts with groups of four and counts, over
+        // its first 32 windows, the selected matches of 24 bytes and more: fewer than one in sixteen windows -> groups of two
+        // from there on.  With groups of two every extension is counted (it is the slow path anyway): more than one in
+        // eight windows -> back to four, for the rest of the block.  The steady state of either shape carries no counting.
+        int shape = (ENC_GROUPS == 2) ? 2 : 4;
+        auto shape_update = [&]() {
+            if (ENC_GROUPS != 0) return;
+            if (shape == 4) {
+                if (shapeCounting && shapeWin >= 32) {
+                    shapeCounting = false;
+                    if (shapeLong * 16 < shapeWin) { shape = 2; shapeWin = 0; shapeExt = 0; }
+                }
+            } else if (shapeWin >= 64) {
+                if (shapeExt * 8 > shapeWin) shape = 4;                 // (shapeCounting stays off: four for the rest of the block)
+                shapeWin = 0; shapeExt = 0;
+            }
+        };
         // ---- one window per step: positions [p0, p0 + 64), p0 >= max(anchor, 8); returns where the next one starts.
         // The probed positions outside the selected matches go into the table afterwards (:998, the reference's policy).
         // the last request of a window ends 136 bytes behind its first position
         auto pipe_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 >= 8 && p0 + 136 <= n && pipeFits; };
-        auto group_window = [&](const int p0) -> int {
+        auto group_window = [&](auto G, const int p0) -> int {
             const uint32_t pos = (uint32_t)(p0 + lane), pos8 = pos - 8u;
             if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos);
             LW W;
             lw_probe(W, pos, pfV8, false);
-            lw_heads(W, pos, pos8, 0u, 0ull);
-            lw_loads(W, p0);
+            lw_heads(G, W, pos, pos8, 0u, 0ull);
+            lw_loads(G, W, p0);
             ENC_LAP(0);
             commit_pending();                                  // (the requests are out: the last window's moves are looked at now)
-            lw_measure(W, p0);
-            lw_hits(W, p0, hc0, (uint32_t)lane + 8u, 0u);
+            lw_measure(G, W, p0);
+            lw_hits(G, W, p0, hc0, (uint32_t)lane + 8u, 0u);
             if (!W.hitm) {
                 // nothing here: every position is registered, the miss counter widens the stride (:957-967)
                 lw_insert(W, pos);
@@ -736,6 +795,8 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             int pEnd = anchor;
             const uint64_t selm = lw_select(W, p0, pEnd);
+            shapeWin += 1;
+            if (shapeCounting) shapeLong += (int)__builtin_popcountll(selm & W.longm);
             ENC_LAP(1);
             // the next window starts at the end of the last match, or where this one ends: its bytes are requested now
             const int nextP = max(p0 + LZ4_WAVE, pEnd);
@@ -771,26 +832,28 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         auto pair_can_issue = [&](int p0) -> bool { return (missAcc >> 6) == 1u && p0 >= 8 && p0 + 200 <= n && pipeFits; };
         // (the caller has the pair's bytes in pfV8 / pfV8b; go = the next pair can start at the returned position, and its
         // bytes are on their way)
-        auto pair_window = [&](const int p0, bool &go) -> int {
+        auto pair_window = [&](auto G, const int p0, bool &go) -> int {
             const int p1 = p0 + LZ4_WAVE;
             const uint32_t pos0 = (uint32_t)(p0 + lane), pos1 = pos0 + 64u;
             LW W0, W1;
             lw_probe(W0, pos0, pfV8, true);
             lw_probe(W1, pos1, pfV8b, true);
-            lw_heads(W0, pos0, pos0 - 8u, 0u, 0ull);
-            lw_heads(W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63);   // (lane 0 may continue the run of the last lane of the window before it)
-            lw_loads(W0, p0);
-            lw_loads(W1, p1);
+            lw_heads(G, W0, pos0, pos0 - 8u, 0u, 0ull);
+            lw_heads(G, W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63);   // (lane 0 may continue the run of the last lane of the window before it)
+            lw_loads(G, W0, p0);
+            lw_loads(G, W1, p1);
             ENC_LAP(0);
             commit_pending();                                  // the pair before this one: its moves' results are looked at now
             int pEnd = anchor;
-            lw_measure(W0, p0);
-            lw_measure(W1, p1);
-            lw_hits(W0, p0, hc0, (uint32_t)lane + 8u, 0u);
+            lw_measure(G, W0, p0);
+            lw_measure(G, W1, p1);
+            lw_hits(G, W0, p0, hc0, (uint32_t)lane + 8u, 0u);
             const uint64_t sel0 = lw_select(W0, p0, pEnd);
             const int pMid = pEnd;
-            lw_hits(W1, p1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
+            lw_hits(G, W1, p1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
             const uint64_t sel1 = lw_select(W1, p1, pEnd);
+            shapeWin += 2;
+            if (shapeCounting) shapeLong += (int)__builtin_popcountll(sel0 & W0.longm) + (int)__builtin_popcountll(sel1 & W1.longm);
             ENC_LAP(1);
             // the next pair starts at the end of the last match, or where this one ends: its bytes are requested now
             const int nextP = max(p0 + 2 * LZ4_WAVE, pEnd);
@@ -840,9 +903,21 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                         if (pfPos != np) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + lane));
                         pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + LZ4_WAVE + lane));
                         bool go = true;
-                        do np = pair_window(np, go); while (go);
+                        while (go) {
+                            if (shape == 4) {
+                                do { np = pair_window(EncGroups<4>{}, np, go); shape_update(); } while (go && shape == 4);
+                            } else {
+                                do { np = pair_window(EncGroups<2>{}, np, go); shape_update(); } while (go && shape == 2);
+                            }
+                        }
                     } else {
-                        do np = group_window(np); while (pipe_can_issue(np));
+                        do {
+                            if (shape == 4) {
+                                do { np = group_window(EncGroups<4>{}, np); shape_update(); } while (shape == 4 && pipe_can_issue(np));
+                            } else {
+                                do { np = group_window(EncGroups<2>{}, np); shape_update(); } while (shape == 2 && pipe_can_issue(np));
+                            }
+                        } while (pipe_can_issue(np));
                     }
                     commit_pending();
                     p = np;
