@@ -812,7 +812,8 @@ __global__ __launch_bounds__(256) void k_twin_begin(DecodeArgs a)
     const int p = (int)(blockIdx.x * 256u + threadIdx.x);
     if (p >= nPieces) return;
     const int b0 = a.segFirst + p * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
-    if (twin_true_dict(a, b0)) {
+    // (one THREAD per piece here: not twin_true_dict, whose answer is made wave-uniform for the kernels that run a wave per piece)
+    if (b0 == a.segFirst || a.result[b0 - 1] > 0) {
         a.twinCtl[2 + p] = 2u;                                   // final; its results are published by k_twin_publish
     } else {
         a.twinCtl[2 + p] = 0u;
