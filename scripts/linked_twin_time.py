@@ -12,7 +12,7 @@ bl = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 O = Oracle(); eng = S.Engine(0); dev = torch.device("cuda:0")
 t0 = time.time()
 # a few hundred distinct blocks cycled with a stride keep the host compression short; the stream is still one linked stream
-base_n = min(nb, 2048)
+base_n = nb if os.environ.get("TWIN_DISTINCT") else min(nb, 2048)
 data = O.gen(kind, base_n, bl, first_block=7).tobytes()
 data = (data * ((nb + base_n - 1) // base_n))[: nb * bl]
 fr = O.frame_compress(data, bl, 1, 8, True)

@@ -713,8 +713,9 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // where the pieces fill the chip anyway: spans of 12 288 blocks and more (measured on text, 64 KiB blocks: 16 384
     // blocks 12.5 against 16.2 ms for the pointer pass; 4 096 blocks would take 10 against 4.5 ms).
     // MI355LZ4_LINKED_TWIN: 0 = never, 1 = whenever it applies (the tests); MI355LZ4_LINKED_TWIN_PIECE: blocks per
-    // piece (default 12 below 20 480 blocks, 16 above: with 8 the taint reaches a piece's last block often enough to chain
-    // the pieces' second halves -- 1 GiB of text: 28 ms with 8, 11.7 with 12, 12.5 with 16; 4 GiB: 80 / 41 / 32 ms).
+    // piece (default 14 below 20 480 blocks, 16 above: with fewer the taint reaches a piece's last block often enough to
+    // chain the pieces' second halves -- 1 GiB of text, 16 384 distinct blocks: 15.8 ms with 10, 14.3 with 12, 12.1 with 14,
+    // 12.5 with 16, 13.7 with 20; 4 GiB: 80 ms with 8, 41 with 12, 32 with 16).
     {
         const char *envTwin = getenv("MI355LZ4_LINKED_TWIN"), *envPiece = getenv("MI355LZ4_LINKED_TWIN_PIECE");
         const bool plain = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS");
@@ -723,7 +724,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                              (envTwin ? atoi(envTwin) != 0 : (plain && span0 >= 12288));
         if (useTwin) {
             const uint64_t stride = (((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u) * 65536u;
-            const int piece = (envPiece && atoi(envPiece) > 0) ? atoi(envPiece) : (span0 < 20480 ? 12 : 16);
+            const int piece = (envPiece && atoi(envPiece) > 0) ? atoi(envPiece) : (span0 < 20480 ? 14 : 16);
             // a piece's wave polls for the piece in front for up to ~20 ms (s_sleep 64 = 4096 cycles a poll) as long as every
             // piece of the launch has a wave slot of its own (256 CUs x 8 waves at least): no wave waits for one not yet started
             const char *envSpin = getenv("MI355LZ4_LINKED_TWIN_SPIN");

@@ -202,13 +202,13 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
     be the input, and the same bytes as the pointer pass's (MI355LZ4_LINKED_TWIN=0).  Rates go to linked_rate.json."""
     import torch
     dev = torch.device("cuda:0")
-    # Two copies of one stream of 6144 blocks laid end to end: still ONE valid linked stream, because the reference wrote the
-    # copy's first block without a dictionary.  That block (index 6144) decodes in the first pass; 6144 = 12 * 512 puts it
-    # at the END of piece 511 (pieces of 12 start at the first dependent block, 1), so that piece 512 -- the first of its
+    # Two copies of one stream of 6272 blocks laid end to end: still ONE valid linked stream, because the reference wrote the
+    # copy's first block without a dictionary.  That block (index 6272) decodes in the first pass; 6272 = 14 * 448 puts it
+    # at the END of piece 447 (pieces of 14 start at the first dependent block, 1), so that piece 448 -- the first of its
     # wave in k_twin_begin -- has its TRUE dictionary in the middle of a segment: the case a wave-uniform shortcut got wrong
     # in development (the 63 pieces behind it were marked final by their wave's first lane; bench.py's check found it).
     # The last piece is ragged.
-    bl, nb1, base = 65536, 6144, 1024
+    bl, nb1, base = 65536, 6272, 1024
     d1 = oracle.gen("text", base, bl, first_block=555).tobytes()
     d1 = (d1 * ((nb1 + base - 1) // base))[: nb1 * bl]
     fr1 = oracle.frame_compress(d1, bl, 1, 8, True)
@@ -216,7 +216,7 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
     for _ in range(extra):
         cut += 8 + int.from_bytes(fr1[cut:cut + 4], "little")
     data, fr, nb = d1 + d1 + d1[: extra * bl], fr1 + fr1 + fr1[:cut], 2 * nb1 + extra
-    assert nb - 1 >= 12288 and nb1 % 12 == 0
+    assert nb - 1 >= 12288 and nb1 % 14 == 0 and (nb1 // 14) % 64 == 0
     offs = np.zeros(nb + 1, dtype=np.int64)
     pos = 0
     for i in range(nb):
