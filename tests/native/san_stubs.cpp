@@ -7,7 +7,9 @@
 #define UNREACHABLE_LAUNCH abort()
 void launch_decode_seq(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_decode_par(const DecodeArgs &, unsigned long long *, hipStream_t) { UNREACHABLE_LAUNCH; }
+#ifdef MI355LZ4_EXPERIMENTS
 void launch_decode_tok(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+#endif
 void launch_linked_tolerant(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_resolve(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_resolve_a(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
@@ -16,6 +18,9 @@ void launch_linked_fetch_block(const DecodeArgs &, hipStream_t) { UNREACHABLE_LA
 size_t ptr_ctl_last_open_offset() { return 0; }
 void launch_longest_stream(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_runs(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_link_stat(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_twin_decode(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_twin_fix(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 size_t tol_region_bytes() { return 65536; }
 void launch_encode(const EncodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_encode_seg(const EncodeSegArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
