@@ -465,6 +465,10 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 // nodes per lane of the next batch: enough window for 64 sequences of this batch's average size
                 const int need = (ipNext - ip) * LZ4_WAVE;             // compressed bytes of 64 such sequences, times nseq
                 nodesPerLane = (need <= PAR_ADAPT6 * nseq) ? 6 : ((need <= 520 * nseq || !PAR_ADAPT10) ? 8 : 10);
+            } else if (PAR_ADAPT && !fromList && nodesPerLane == 6 && !((__ballot(has) >> nseq) & 1ull)) {
+                // a short batch because the narrow window held no further token (not because a sequence was not plain): the
+                // sequences have grown -- fewer than 16 fit 384 candidates -- and the rule above would never look again
+                nodesPerLane = 8;
             }
             const uint32_t mdA = (uint32_t)(dpos - ringBase) + A;   // ring index of my match destination
             const bool ext = TOL && spos < 0;                       // source starts in the previous block: deferred
