@@ -1,22 +1,26 @@
 // encode_wave.hpp -- LZ4 block compressor, one wavefront per block.
 //
 // Replaces (per block) LZ4_compress_fast_continue -> LZ4_compress_generic
-// (reference cbits/lz4.c:1565-1637, 851-1240) for INDEPENDENT blocks.
+// (reference cbits/lz4.c:1565-1637, 851-1240): independent blocks, or (DICT) blocks
+// linked to the block in front of them; SEG: a block cut into segments for small batches.
 //
-// It is not a transcription of the reference's serial probe loop.  The wave
-// probes 64 positions at once:
-//   * lane i hashes the 5 bytes at p + i*step with the reference's hash
-//     (cbits/lz4.c:706-716, hashLog 12) and looks its candidate up in a
-//     4096-entry table held in LDS (16-bit entries: positions for blocks <= 64 KiB,
-//     positions modulo 64 Ki above; cbits/lz4.h:578-580 is the table being replaced);
-//   * a ballot picks the first lane whose candidate verifies (4 equal bytes
-//     within 65535, cbits/lz4.c:1003-1012); lanes up to and including it
-//     publish their positions to the table -- later lanes do not, so the
-//     table never holds a position ahead of the parse;
-//   * the match is extended backwards ("catch up", :1019) and forwards
-//     (LZ4_count, :603-626) by ballot + count-trailing-zeros, 64 bytes a step;
-//   * token / lengths / offset are emitted exactly as :1022-1046, :1065-1135,
-//     literals are copied by all lanes.
+// It is not a transcription of the reference's serial probe loop.  Three forms of a
+// window of probes live in encode_block_wave, picked by what the block is doing:
+//   * dense windows (acceleration 1, matches being found: nearly all of a compressible
+//     block): 64 consecutive positions per window -- two windows per step for blocks of up
+//     to 64 KiB -- hashed with the reference's hash (cbits/lz4.c:706-716, hashLog 12) into a
+//     4096-entry LDS table of 16-bit positions with a 4-bit tag per entry
+//     (cbits/lz4.h:578-580 is the table being replaced); every run head verified and measured
+//     by a group of four (or two) lanes in ONE round trip, greedy selection by a scalar loop,
+//     EVERY match of the window emitted.  The section "Dense window, one round trip" below;
+//     DESIGN.md section 0a has its instruction inventory;
+//   * the per-lane dense window of round 2 (a block's first window and its last 200 bytes);
+//   * strided windows (acceleration > 1, or after a miss streak): a ballot picks the FIRST
+//     lane whose candidate verifies (4 equal bytes within 65535, :1003-1012), lanes up to it
+//     publish their positions, the match is extended backwards ("catch up", :1019) and
+//     forwards (LZ4_count, :603-626) by the whole wave.
+// Sequences are parked one per lane and emitted 64 at a time exactly as :1022-1046,
+// :1065-1135 (emit_sequences).
 // Acceleration keeps the reference meaning (:634, :957-967): the probe stride
 // is (accel*64 + misses) >> 6, with 64 misses charged per fruitless window; the
 // first three probes after a match are adjacent, as in the reference.
