@@ -849,6 +849,22 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             ENC_LAP(0);
             commit_pending();                                  // the pair before this one: its moves' results are looked at now
             int pEnd = anchor;
+#ifdef ENC_EXP_EXTRA_SALU
+            {   // experiment: ENC_EXP_EXTRA_SALU scalar instructions more per pair -- is the scalar unit a limit?
+                int dummy = p0;
+#pragma unroll
+                for (int i = 0; i < ENC_EXP_EXTRA_SALU; i++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy));
+                asm volatile("" : : "s"(dummy));
+            }
+#endif
+#ifdef ENC_EXP_EXTRA_VALU
+            {
+                int dummy = lane;
+#pragma unroll
+                for (int i = 0; i < ENC_EXP_EXTRA_VALU; i++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+                asm volatile("" : : "v"(dummy));
+            }
+#endif
             lw_measure(G, W0, p0);
             lw_measure(G, W1, p1);
             lw_hits(G, W0, p0, hc0, (uint32_t)lane + 8u, 0u);
