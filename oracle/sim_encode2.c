@@ -251,7 +251,8 @@ static int sim_pipe(const uint8_t *src, int n, int accel)
 // ------------------------------------------------------------------ pair form (round 3, ENC_PAIR)
 // Two windows per step: both probed with every position written at once (W0 then W1), finished in order, covered
 // positions take their insertion back (W1 first), the next pair starts at the end of the last selected match.
-static int LATECONTIN = 0;      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
+static int LATECONTIN = 0;
+static int BLINDBACK = 0;     // pair: covered positions put the old entry back without looking whether the bucket still holds them      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
 static int sim_pair(const uint8_t *src, int n, int accel)
 {
     static Ent table[4096];
@@ -318,7 +319,7 @@ static int sim_pair(const uint8_t *src, int n, int accel)
             for (int l = 127; l >= 0; l--) {
                 Ent *e = &table[h[l]];
                 if (late[l]) { if (!covered[l] && (!e->used || e->pos < (uint16_t)(p0 + l))) { Ent x = { (uint16_t)(p0 + l), (uint8_t)tg[l], 1 }; *e = x; } }
-                else if (covered[l]) { if (e->used && e->pos == (uint16_t)(p0 + l)) *e = old[l]; }
+                else if (covered[l]) { if (BLINDBACK || (e->used && e->pos == (uint16_t)(p0 + l))) *e = old[l]; }
             }
             if (any) anchor = pEnd;
             p0 = p0 + 128 > pEnd ? p0 + 128 : pEnd;
@@ -357,7 +358,7 @@ int main(int argc, char **argv)
     TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
     TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
     TAGBITS = 4; WIN = 128; RUN("cur tag4 win128", sim_cur(blocks[b], bl, 1)); WIN = 64;
-    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; HEADCAP = 1000;
+    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; BLINDBACK = 1; RUN("pair tag4 blind takeback", sim_pair(blocks[b], bl, 1)); BLINDBACK = 0; HEADCAP = 1000;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)

@@ -746,11 +746,12 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             table[W.hx >> 4] = (TabT)pos;
             lds_mskor_tag(table, W.hx >> 7, W.tmask, W.tbits);
         };
-        auto lw_takeback = [&](const LW &W, const uint32_t pos, const uint32_t now) {
-            if (now == (pos & (uint32_t)(TabT)~(TabT)0)) {
-                table[W.hx >> 4] = (TabT)W.oldp;
-                lds_mskor_tag(table, W.hx >> 7, W.tmask, W.tagWord & W.tmask);
-            }
+        // (Blind: the bucket is not looked at first.  Where another position of the pair has taken the bucket since, that
+        // entry is lost to the older one -- oracle/sim_encode2.c, "blind takeback": ratio 2.8839 -> 2.8836 / 1.8382 -> 1.8393 --
+        // and the step's chain of dependent waits is one LDS round trip shorter.)
+        auto lw_takeback = [&](const LW &W) {
+            table[W.hx >> 4] = (TabT)W.oldp;
+            lds_mskor_tag(table, W.hx >> 7, W.tmask, W.tagWord & W.tmask);
         };
         const uint32_t hc0 = (((uint32_t)lane + 1u) << 16) | (uint32_t)lane, hc1 = hc0 + ((64u << 16) | 64u);
 
@@ -888,19 +889,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const bool cov0 = lw_finish(W0, pos0, pos0 - 8u, (uint32_t)lane + 1u, sel0, anchor, 0);
             const bool cov1 = lw_finish(W1, pos1, pos1 - 8u, (uint32_t)lane + 65u, sel1, pMid, 1);
             // positions strictly inside a selected match take their insertion back if the bucket still holds it
-            // (ENC_EXP_TAKEBACK_TOGETHER reads both buckets before either is written -- one LDS round trip for the pair; where
-            // the two windows met in ONE bucket and both positions are covered, the first window's then stays registered.
-            // Measured: lzsynth ratio 2.894 -> 2.904, encode +1 %, but the stream decodes 2 % slower: off)
-#ifdef ENC_EXP_TAKEBACK_TOGETHER
-            const uint32_t now1 = table[W1.hx >> 4], now0 = table[W0.hx >> 4];
-            if (cov1) lw_takeback(W1, pos1, now1);
+            // (last window first: where the two met in one bucket the first window's older entry is the one to come back)
+            if (cov1) lw_takeback(W1);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (cov0) lw_takeback(W0, pos0, now0);
-#else
-            if (cov1) lw_takeback(W1, pos1, table[W1.hx >> 4]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (cov0) lw_takeback(W0, pos0, table[W0.hx >> 4]);
-#endif
+            if (cov0) lw_takeback(W0);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             ENC_LAP(3);
             if (sel0 | sel1) { anchor = pEnd; missAcc = miss0; }
