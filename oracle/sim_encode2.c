@@ -252,7 +252,8 @@ static int sim_pipe(const uint8_t *src, int n, int accel)
 // Two windows per step: both probed with every position written at once (W0 then W1), finished in order, covered
 // positions take their insertion back (W1 first), the next pair starts at the end of the last selected match.
 static int LATECONTIN = 0;
-static int BLINDBACK = 0;     // pair: covered positions put the old entry back without looking whether the bucket still holds them      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
+static int BLINDBACK = 0;
+static int DROP2ND = 0;       // pair: a window with more than 16 heads verifies its primary heads (left neighbour without a candidate) first and drops what does not fit 16 groups     // pair: covered positions put the old entry back without looking whether the bucket still holds them      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
 static int sim_pair(const uint8_t *src, int n, int accel)
 {
     static Ent table[4096];
@@ -281,6 +282,27 @@ static int sim_pair(const uint8_t *src, int n, int accel)
             }
             g_windows += 2;
             int hd = 0, nh[2] = {0, 0};
+            int drop[128]; memset(drop, 0, sizeof drop);
+            if (DROP2ND) for (int w = 0; w < 2; w++) {
+                int tot = 0, prim = 0;
+                for (int l = 64 * w; l < 64 * w + 64; l++) {
+                    int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
+                    if (candOk[l] && !contin) { tot++; if (!(l > 0 && candOk[l - 1])) prim++; }
+                }
+                if (tot > 16) {
+                    int room = 16 - prim;                       // groups left for secondary heads, in lane order
+                    int pr = 0;
+                    for (int l = 64 * w; l < 64 * w + 64; l++) {
+                        int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
+                        if (!(candOk[l] && !contin)) continue;
+                        int secondary = l > 0 && candOk[l - 1];
+                        if (!secondary) { if (++pr > 16) drop[l] = 1; }
+                        else if (room > 0) room--;
+                        else drop[l] = 1;
+                    }
+                    g_ext2++;
+                }
+            }
             for (int l = 0; l < 128; l++) {
                 hit[l] = 0; ml[l] = 0; hback[l] = 0; headOf[l] = 0;
                 int contin = candOk[l] && l > 0 && candOk[l - 1] && cand[l] == cand[l - 1] + 1;
@@ -288,7 +310,7 @@ static int sim_pair(const uint8_t *src, int n, int accel)
                 int pos = p0 + l;
                 if (head) {
                     hd = l; headOf[l] = 1; nh[l >> 6]++; g_heads++;
-                    if (nh[l >> 6] <= HEADCAP && rd32(src + pos) == rd32(src + cand[l])) {
+                    if (!drop[l] && nh[l >> 6] <= HEADCAP && rd32(src + pos) == rd32(src + cand[l])) {
                         hit[l] = 1;
                         int maxLen = matchlimit - pos;
                         int m = count_fwd(src, pos, cand[l], matchlimit);
@@ -358,7 +380,7 @@ int main(int argc, char **argv)
     TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
     TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
     TAGBITS = 4; WIN = 128; RUN("cur tag4 win128", sim_cur(blocks[b], bl, 1)); WIN = 64;
-    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; BLINDBACK = 1; RUN("pair tag4 blind takeback", sim_pair(blocks[b], bl, 1)); BLINDBACK = 0; HEADCAP = 1000;
+    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; BLINDBACK = 1; RUN("pair tag4 blind takeback", sim_pair(blocks[b], bl, 1)); BLINDBACK = 0; HEADCAP = 1000; DROP2ND = 1; RUN("pair tag4 one round, primary heads first", sim_pair(blocks[b], bl, 1)); DROP2ND = 0; HEADCAP = 16; RUN("pair tag4 headcap16", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; HEADCAP = 1000;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)

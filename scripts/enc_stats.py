@@ -16,5 +16,5 @@ S.lib.mi355lz4_debug_stats(eng.ctx, 1, buf)
 eng.compress_batch_device(src, NB, BL, slots, stride, flen); eng.synchronize()
 S.lib.mi355lz4_debug_stats(eng.ctx, 0, buf)
 v = list(buf)[:8]; w = max(v[6], 1)
-names = ["0:probe+heads+requests issued", "1:wait+lengths+select", "2:next bytes requested", "3:finish+queue moves+table", "4:-", "5:-", "windows", "heads"]
+names = ["0:probe+heads+requests issued", "1:wait+lengths+select", "2:next bytes requested", "3:finish+queue moves+table", "4:wait for the windows bytes", "5:hash + table round trip", "windows", "heads"]
 print(kind, "linked" if linked else "independent", "windows/block %.0f" % (w / NB), " cycles/window:", {n: round(x / w) for n, x in zip(names, v) if n != "windows"})

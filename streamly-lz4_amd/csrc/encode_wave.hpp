@@ -841,8 +841,16 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const int p1 = p0 + LZ4_WAVE;
             const uint32_t pos0 = (uint32_t)(p0 + lane), pos1 = pos0 + 64u;
             LW W0, W1;
+#ifdef ENC_STATS
+            { uint32_t x = (uint32_t)pfV8 ^ (uint32_t)pfV8b; asm volatile("" : "+v"(x)); }      // the bytes have arrived
+            ENC_LAP(4);
+#endif
             lw_probe(W0, pos0, pfV8, true);
             lw_probe(W1, pos1, pfV8b, true);
+#ifdef ENC_STATS
+            { uint32_t x = W0.oldp ^ W1.oldp ^ W0.tagWord ^ W1.tagWord; asm volatile("" : "+v"(x)); }   // the table has answered
+            ENC_LAP(5);
+#endif
             lw_heads(G, W0, pos0, pos0 - 8u, 0u, 0ull);
             lw_heads(G, W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63);   // (lane 0 may continue the run of the last lane of the window before it)
             lw_loads(G, W0, p0);
