@@ -28,6 +28,23 @@ def test_library_exports_every_declared_symbol(slz4):
     assert slz4.lib.mi355lz4_version() == 100
 
 
+def test_shipped_library_carries_no_experiments(slz4):
+    """`make lib` leaves the shelved experiments out (decoder variant 3's kernels and launcher); `make lib-exp` has them.
+    Checked on the binaries: the capability query and the launcher's symbol."""
+    import subprocess
+    if os.environ.get("MI355LZ4_LIB"):
+        pytest.skip("another library was chosen by MI355LZ4_LIB")
+    assert not slz4.Engine.has_experiments()
+    lib_dir = os.path.join(ROOT, "streamly-lz4_amd", "lib")
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(lib_dir, "libmi355lz4.so")], capture_output=True, text=True).stdout
+    assert "mi355lz4_set_decoder" in syms and "launch_decode_tok" not in syms
+    exp = os.path.join(lib_dir, "libmi355lz4_exp.so")
+    if os.path.exists(exp):
+        e = C.CDLL(exp)
+        e.mi355lz4_debug_has_experiments.restype = C.c_int
+        assert e.mi355lz4_debug_has_experiments() == 1
+
+
 def test_bound_and_stride(slz4, oracle):
     for n in (0, 1, 255, 65536, 262144, 0x7E000000):
         assert slz4.compress_bound(n) == oracle.compress_bound(n) == slz4.lib.LZ4_compressBound(n)
