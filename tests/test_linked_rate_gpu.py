@@ -251,3 +251,29 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
         f.write(json.dumps(rec) + "\n")
     print(rec)
     assert rates["twin (default)"] > rates["pointer pass"]
+    # The same stream with payload bytes of three blocks corrupted: whatever the twin decode does with it (a block that fails
+    # with its true dictionary sends the rest of the span to the pointer pass), results and bytes must be those of the
+    # pointer pass alone -- which tests/test_parity_gpu.py holds against the oracle's codes on short streams.
+    bad = buf.clone()
+    for blk in (5000, 5001, nb - 3):
+        p0 = int(offs[blk]) + 8
+        n = int(offs[blk + 1]) - p0
+        bad[p0 + n // 2:p0 + n // 2 + 48] = 0xff           # (tokens of 0xff: length fields that run past the block)
+    outs = {}
+    for label, env in (("twin", None), ("pointer", "0")):
+        if env is None:
+            monkeypatch.delenv("MI355LZ4_LINKED_TWIN", raising=False)
+        else:
+            monkeypatch.setenv("MI355LZ4_LINKED_TWIN", env)
+        out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
+        r = torch.zeros(nb, dtype=torch.int32, device=dev)
+        engine.decompress_batch_device(bad, len(fr), off, nb, out, ooff, r, linked=True)
+        engine.synchronize()
+        outs[label] = (r.cpu().numpy().copy(), out)
+    r_t, o_t = outs["twin"]
+    r_p, o_p = outs["pointer"]
+    assert (r_t == r_p).all(), np.nonzero(r_t != r_p)[0][:8]
+    assert (r_p <= 0).any()                                  # (the corruption was felt)
+    good = torch.from_numpy((r_p == bl)).to(dev)
+    same = (o_t.view(nb, bl) == o_p.view(nb, bl)).all(dim=1)
+    assert bool((same | ~good).all().item())
