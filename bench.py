@@ -20,7 +20,11 @@ the target; its `ratio` is the reference's compressed size for the same data.
 
 N>1 also runs the RCCL ordered gather of the framed output once (untimed by `value`), decodes the gathered
 stream on the root and compares it with the generator's global stream, and reports compute-only and
-compute+gather rates.
+compute+gather rates, the gather's own rate against the root's xGMI links and `roundtrip_plus_gather_GBps`.
+
+BASELINE config 4 (64 GiB over 8 GPUs) is 8 GiB per GPU: `--workload roundtrip --blocks 131072` runs that share
+(131 072 blocks of 64 KiB compressed, compacted and decoded in one call each); rehearsed at N = 1
+(profiles/r05_bench_roundtrip_8GiB.json).  At N = 8 the root's verification decodes 8 x that in one call.
 """
 import argparse
 import json
