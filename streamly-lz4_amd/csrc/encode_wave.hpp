@@ -553,7 +553,26 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     while (d < r && gsrc[pe + off + (int)d] == gsrc[ce + off + (int)d]) d++;
                 }
                 const uint64_t ne = ~enc_ballot(full);
-                if (ne == 0ull) { total += 16 * LZ4_WAVE; continue; }
+                if (ne == 0ull) {
+                    total += 16 * LZ4_WAVE;
+                    // A whole KiB was equal: a long run (zero pages, sparse files).  From here ENC_EXTEND_STRIDES KiB a
+                    // round trip while all of it is equal; the first unequal stretch goes back to the exact loop above.
+#ifndef ENC_EXTEND_STRIDES
+#define ENC_EXTEND_STRIDES 2   /* (4: the pair form spills) */
+#endif
+                    while (total + ENC_EXTEND_STRIDES * 16 * LZ4_WAVE <= maxExtra) {
+                        uint32_t diff = 0;
+#pragma unroll
+                        for (int u = 0; u < ENC_EXTEND_STRIDES; u++) {
+                            const int o = total + u * 16 * LZ4_WAVE + 16 * lane;
+                            const dev_v4 a = load16((uint32_t)(pe + o)), b = load16((uint32_t)(ce + o));
+                            diff |= (a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w);
+                        }
+                        if (enc_ballot(diff != 0u) != 0ull) break;
+                        total += ENC_EXTEND_STRIDES * 16 * LZ4_WAVE;
+                    }
+                    continue;
+                }
                 const int first = (int)__builtin_ctzll(ne);
                 total += 16 * first + __builtin_amdgcn_readlane((int)d, first);
                 break;
@@ -963,6 +982,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 // bytes (:1009, LZ4_count :603-626); the others derive hit and length from it.  This keeps
                 // the scattered candidate loads to roughly one per real match plus the unmatched positions.
                 bool hit = false;
+                bool longRun = false;     // the lane's own counting stopped at ENC_LANE_CAP bytes with the match still running
                 uint32_t hback = 0;       // head only: equal bytes just before the match (catch up, :1019), 0..8
                 int myHead = 0;
                 {
@@ -990,7 +1010,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                             uint32_t m = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
                             if (m == 8u) {
                                 bool more = true;
-                                while (more && m + 32u <= maxLen) {               // 32 bytes a step
+                                // (a lane counts at most ENC_LANE_CAP bytes on its own, 32 a round trip: a match that is still
+                                // running there -- a zero page took one lane 2048 round trips -- is finished by the whole wave,
+                                // 1 KiB a step, if the selection takes it)
+#ifndef ENC_LANE_CAP
+#define ENC_LANE_CAP 256u
+#endif
+                                while (more && m + 32u <= maxLen && m < ENC_LANE_CAP) {               // 32 bytes a step
                                     uint4 a0, a1, b0, b1;
                                     __builtin_memcpy(&a0, src + myPos + m, 16);
                                     __builtin_memcpy(&a1, src + myPos + m + 16, 16);
@@ -1001,6 +1027,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                                     m += d;
                                     more = (d == 32u);
                                 }
+#ifndef ENC_NO_PIPE
+                                if (more && m >= ENC_LANE_CAP) { longRun = true; more = false; }
+#endif
                                 while (more && m + 16u <= maxLen) {
                                     uint4 a0, b0;
                                     __builtin_memcpy(&a0, src + myPos + m, 16);
@@ -1020,12 +1049,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #endif
                     const uint64_t below = headm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
                     myHead = below ? 63 - (int)__builtin_clzll(below) : 0;
-                    const int headInfo = par_free_bperm((int)(myMl | (hback << 16)), myHead);   // 0 when the head missed
+                    const int headInfo = par_free_bperm((int)(myMl | (hback << 16) | ((uint32_t)longRun << 24)), myHead);   // 0 when the head missed
                     if (contin) {
                         const int m = (headInfo & 0xffff) - (lane - myHead);
                         hit = m >= LZ4_MINMATCH;
                         myMl = hit ? (uint32_t)m : 0u;
-                        hback = (uint32_t)headInfo >> 16;
+                        hback = ((uint32_t)headInfo >> 16) & 0xffu;
+                        longRun = hit && ((headInfo >> 24) & 1);
                     }
                 }
                 ENC_LAP(1);
@@ -1043,9 +1073,17 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 // the selected match before it -- is fetched afterwards with one cross-lane read.
                 uint64_t selm = 0;
                 int pEnd = anchor;
+                const uint64_t longm = __ballot(hit && longRun);
                 for (uint64_t hm = hitm; hm;) {
                     const int k = (int)__builtin_ctzll(hm);
-                    const int endk = p0 + k + (int)__builtin_amdgcn_readlane((int)myMl, k);
+                    int len = (int)__builtin_amdgcn_readlane((int)myMl, k);
+#ifndef ENC_NO_PIPE
+                    if ((longm >> k) & 1ull) {
+                        len += extend_long(p0 + k + len, __builtin_amdgcn_readlane((int)cand, k) + len);
+                        myMl = (uint32_t)enc_writelane((int)myMl, len, k);
+                    }
+#endif
+                    const int endk = p0 + k + len;
                     selm |= 1ull << k;
                     pEnd = endk;
                     const int sh = endk - p0;
