@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "streamly-lz4_amd"))
 import numpy as np, torch
 import streamly_lz4_amd as S
-dev = torch.device("cuda:0"); eng = S.Engine(0); BL = 65536; NB = 4096
+dev = torch.device("cuda:0"); eng = S.Engine(0); BL = 65536; NB = 16384
 rng = np.random.default_rng(1)
 cases = {
     "zeros": np.zeros(NB * BL, np.uint8),

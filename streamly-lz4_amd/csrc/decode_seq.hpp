@@ -45,6 +45,21 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dstGeneric, int op, int
             }
             wave_fence();
         }
+    } else if (match >= 0 && ml > LZ4_WAVE) {
+        // Short period, long match (runs, zero pages, records): the period -- at most 63 bytes, all of it in front of this
+        // sequence -- is read ONCE, a byte a lane; every output byte is then one of those, fetched from its lane through the
+        // crossbar, and the stores follow each other without a wait in between.  (The loop below it reads the source again
+        // for every 64 bytes and waits for each read with the store before it still in flight: 2 us per 64 bytes.)
+        const uint32_t mine = (lane < offset) ? (uint32_t)dst[match + (int)lane] : 0u;
+        uint32_t idx = lane % offset;                               // source lane of byte `lane` of the current 64
+        const uint32_t step = LZ4_WAVE % offset;                    // ... advances by 64 mod offset per 64 bytes
+#pragma unroll 1
+        for (uint32_t c = 0; c < ml; c += LZ4_WAVE) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)mine);
+            if (c + lane < ml) dst[op + c + lane] = (uint8_t)b;
+            idx += step;
+            idx -= (idx >= offset) ? offset : 0u;
+        }
     } else {
         // short period: every source byte lies in [match, op), complete before this sequence
 #pragma unroll 1
@@ -175,6 +190,16 @@ __device__ __forceinline__ int decode_seq_body(SeqState &st, int maxSeq, const u
 
     for (;;) {
         if (maxSeq > 0) {
+            if (budget == 0 && maxSeq == 1 && fast && ip + 24 < iend) {
+                // Called for ONE sequence by the lane-parallel decoder, which takes only sequences whose lengths have at most
+                // one extension byte.  If the NEXT sequence is not such a one either -- a second length byte: a literal run of
+                // 270 bytes and more, a match of 274 and more -- it would come straight back here after a failed batch, a
+                // call and a reload of the ring (about 15 us a sequence on data made of long runs: 144 GB/s); it is decoded
+                // here and now instead.  (The peek reads the token and one length byte through the window.)
+                const uint32_t t = rd(ip), l = t >> 4;
+                if (l == 15u) { if (rd(ip + 1) == 255u) budget = 1; }
+                else if ((t & 15u) == 15u && ip + 4 + (int)l + 24 < iend && rd(ip + 3 + (int)l) == 255u) budget = 1;
+            }
             if (budget == 0) { st.ip = ip; st.op = op; st.fast = fast; return SEQ_CONTINUE; }
             budget--;
         }
