@@ -507,6 +507,10 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // last looked at
         int shapeWin = 0, shapeLong = 0, shapeExt = 0;
         bool shapeCounting = ENC_GROUPS == 0;
+        // ... and whether the block has runs of equal bytes worth looking for (lw_heads, ENC_SELF_RUN): looked for in the
+        // block's first 32 windows, and from there on only if ENC_SELF_RUN_MIN of those had one
+        bool selfRunOn = true;
+        int selfRunSeen = 0;
         // lane constants of the groups: lane j of a group holds bytes [16 j - 8, 16 j + 8) relative to the head
         // (two shapes, ENC_GROUPS in kernels: the wave switches between them with what the block's matches look like)
         // bit offsets of a lane's four words; a group's lane 0 holds the 8 bytes BEFORE the head in its first two: ~0 keeps
@@ -609,7 +613,16 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         };
-        auto lw_heads = [&](auto G, LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t offBefore, const uint64_t okBefore) {
+#ifndef ENC_SELF_RUN
+#define ENC_SELF_RUN 1
+#endif
+#ifndef ENC_SELF_RUN_MIN
+#define ENC_SELF_RUN_MIN 12    // windows (of the block's first 32) with such a position for the search to stay on
+#endif
+        // lo = the position's first four bytes; loBefore = those of the position in front of lane 0 (anything with another
+        // first byte where that is not known)
+        auto lw_heads = [&](auto G, LW &W, const uint32_t pos, const uint32_t pos8, const uint32_t offBefore, const uint64_t okBefore,
+                            const uint32_t lo, const uint32_t loBefore) {
             constexpr uint32_t GR = decltype(G)::GR; constexpr int GSH = decltype(G)::GSH;
             // (predicates are kept as scalar masks -- one compare each, combined by the scalar unit -- and turned back
             // into lane predicates where a select needs them)
@@ -623,6 +636,22 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             } else {
                 c8 = W.oldp - 8u;                                  // positions stay below 64 Ki: the entry IS the position,
                 okm &= enc_ballot(c8 < pos8);                      // and 8 <= cand < pos in one unsigned compare (:1003-1006)
+            }
+            if (ENC_SELF_RUN && selfRunOn) {
+                // The positions of one window cannot be each other's candidates, so a run of equal bytes -- indentation, zero
+                // fill -- that starts inside a window found no match until the window behind it (the reference reaches the
+                // offset-1 match at the run's second byte).  A position without a table candidate whose four bytes repeat the
+                // byte in front of it takes position - 1: consecutive such positions share the distance, so a run is ONE head.
+                // (oracle/sim_encode2.c, "self runs": source code 3.22 -> 3.29 against the reference's 3.36, text unchanged)
+                // (two instructions for a window without four equal bytes anywhere; the rest behind a scalar branch)
+                uint64_t selfm = enc_ballot(lo == __builtin_amdgcn_perm(lo, lo, 0u)) & ~okm;
+                if (selfm) {
+                    const uint32_t loLeft = (uint32_t)__builtin_amdgcn_update_dpp((int)loBefore, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    selfm &= enc_ballot(((lo ^ loLeft) & 0xffu) == 0u);
+                    if (__builtin_amdgcn_inverse_ballot_w64(selfm)) c8 = pos8 - 1u;
+                    okm |= selfm;
+                    selfRunSeen += selfm != 0ull;
+                }
             }
             W.candm = okm;
             W.c8 = c8;
@@ -787,6 +816,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             if (shape == 4) {
                 if (shapeCounting && shapeWin >= 32) {
                     shapeCounting = false;
+                    selfRunOn = selfRunSeen >= ENC_SELF_RUN_MIN;
                     if (shapeLong * 16 < shapeWin) { shape = 2; shapeWin = 0; shapeExt = 0; }
                 }
             } else if (shapeWin >= 64) {
@@ -803,7 +833,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos);
             LW W;
             lw_probe(W, pos, pfV8, false);
-            lw_heads(G, W, pos, pos8, 0u, 0ull);
+            lw_heads(G, W, pos, pos8, 0u, 0ull, (uint32_t)pfV8, ~(uint32_t)pfV8);
             lw_loads(G, W, p0);
             ENC_LAP(0);
             commit_pending();                                  // (the requests are out: the last window's moves are looked at now)
@@ -870,8 +900,9 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             { uint32_t x = W0.oldp ^ W1.oldp ^ W0.tagWord ^ W1.tagWord; asm volatile("" : "+v"(x)); }   // the table has answered
             ENC_LAP(5);
 #endif
-            lw_heads(G, W0, pos0, pos0 - 8u, 0u, 0ull);
-            lw_heads(G, W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63);   // (lane 0 may continue the run of the last lane of the window before it)
+            lw_heads(G, W0, pos0, pos0 - 8u, 0u, 0ull, (uint32_t)pfV8, ~(uint32_t)pfV8);
+            lw_heads(G, W1, pos1, pos1 - 8u, (uint32_t)__builtin_amdgcn_readlane((int)W0.off, 63), W0.candm >> 63,   // (lane 0 may continue the run of the last lane of the window before it)
+                     (uint32_t)pfV8b, (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pfV8, 63));
             lw_loads(G, W0, p0);
             lw_loads(G, W1, p1);
             ENC_LAP(0);
