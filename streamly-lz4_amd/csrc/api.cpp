@@ -734,19 +734,24 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             if (segBlocks < piece) segBlocks = piece;
             if (segBlocks > span0) segBlocks = (span0 + piece - 1) / piece * piece;
             const size_t nPiecesMax = (size_t)segBlocks / piece + 1;
-            const size_t metaBytes = 131072 + (size_t)segBlocks * 8 + (2 + nPiecesMax) * 4 + 64;
+            const size_t metaBytes = 131072 + (size_t)segBlocks * 12 + (2 + nPiecesMax) * 4 + 64;
             bool done = false;
             if (dev_reserve(c->ptrBuf, (size_t)segBlocks * stride) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0) {
                 uint8_t *meta = (uint8_t *)c->tolMeta.p;
                 a.seamPages = meta; a.twin = (uint8_t *)c->ptrBuf.p; a.twinStride = stride; a.twinPiece = piece;
                 a.twinRes = (int32_t *)(meta + 131072); a.twinTaint = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 4);
-                a.twinCtl = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 8);
+                a.twinCtl = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 12);
+                // the first pass's results of the segment, kept: a segment that does not finish this way gets them back (a piece
+                // is only right if every piece in front of it is -- which dictionary is in force behind a block that fails
+                // depends on that failure -- so a segment with a broken block keeps nothing of what its pieces concluded)
+                int32_t *snap = (int32_t *)(meta + 131072 + (size_t)segBlocks * 8);
                 HIP_TRY(hipMemsetAsync(meta, 0x00, 65536, c->stream));
                 HIP_TRY(hipMemsetAsync(meta + 65536, 0xff, 65536, c->stream));
                 done = true;
                 for (int s0 = first; s0 <= last && done; s0 += segBlocks) {
                     a.segFirst = s0; a.segEnd = (s0 + segBlocks < last + 1) ? s0 + segBlocks : last + 1;
                     if ((a.segEnd - a.segFirst + piece - 1) / piece > 2048) a.twinSpin = 0;
+                    HIP_TRY(hipMemcpyAsync(snap, result + a.segFirst, (size_t)(a.segEnd - a.segFirst) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
                     HIP_TRY(hipMemsetAsync(a.twinCtl, 0, 8, c->stream));
                     launch_twin_decode(a, c->stream);
                     bool segDone = false;
@@ -758,12 +763,15 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                         segDone = stat[0] == 0;
                     }
                     done = segDone;
+                    if (!segDone)
+                        HIP_TRY(hipMemcpyAsync(result + a.segFirst, snap, (size_t)(a.segEnd - a.segFirst) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
                 }
             }
             (void)hipGetLastError();
             if (done) { link_scratch_release(c); return check_launch("decode launch"); }
-            // Not finished this way (a broken block, pieces that never become final, no scratch): what is final is final; the
-            // blocks that still carry the first pass's codec error go through the pointer / serial pass below
+            // Not finished this way (a broken block, pieces that never become final, no scratch): the segments that did finish
+            // are final, the one that did not has its first-pass results back; the blocks that carry the first pass's codec
+            // error go through the pointer / serial pass below
             a.twin = nullptr; a.seamPages = nullptr; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
             a.segFirst = 0; a.segEnd = nBlocks;
             HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));

@@ -722,8 +722,9 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
 // (no differing byte: the normal case with eight blocks per piece) re-decodes its leading blocks with the true
 // dictionary until it reaches a block without a differing byte; pieces whose predecessor is not final yet wait for the
 // next round (k_twin_fix is launched until a counter says that no piece is left).  Anything unusual -- a block that
-// fails with its true dictionary, too many rounds -- leaves the remaining blocks' results as the first pass had them and
-// the caller continues with the pointer pass, which treats what is final as final.
+// fails with its true dictionary, too many rounds -- gives the segment's blocks the first pass's results back (a piece is
+// only right if every piece in front of it is: which dictionary is in force behind a failed block depends on the failure)
+// and the caller continues with the pointer pass, which treats what is final as final.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool twin_true_dict(const DecodeArgs &a, int b0)
 {
@@ -878,6 +879,11 @@ __global__ TWIN_OCC void k_twin_fix(DecodeArgs a)
                     r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
                 r = uni(r);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            } else if (redo && is_codec_error(r0)) {
+                // No dictionary is in force (every block in front failed or was empty): what the stand-in made of this block
+                // does not count -- on its own the block fails, as the first pass found (:2331: a failed block leaves no
+                // dictionary behind)
+                r = r0;
             }
             if (r < 0 && is_codec_error(r)) {
                 // fails with its true dictionary: the stream is broken here.  The block keeps the standalone pass's result and
