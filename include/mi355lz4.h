@@ -170,16 +170,18 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * decode on their own (everything this engine's compressor emits) are final
  * after the parallel kernel; blocks that reach into their predecessor are
  * resolved by a second, data-parallel pass: short runs of them by a wave per
- * run, spans of 12 288 blocks and more by the twin decode (pieces of the span
- * decoded twice with two stand-ins for the missing dictionary, DESIGN.md 0b:
- * scratch 1 byte per output byte of up to 32 768 blocks of 64 KiB at a time),
+ * run, spans of 640 MiB and more by the run-in decode (pieces of the span,
+ * each decoded from a few blocks in front of it and checked against what the
+ * piece in front wrote, DESIGN.md 0b: scratch two blocks per piece, at most
+ * 4096 pieces),
  * everything else through source pointers + pointer jumping (DESIGN.md 1:
  * scratch 1 + 4 bytes per output byte of up to 4096 blocks at a time).  With
  * linked != 0 the call WAITS for the first pass on the engine's stream (it
  * reads back how many blocks need the second pass and sizes it); with
  * linked == 0 it only enqueues work.  Environment knobs of the second pass
  * (read per call; for tests and measurements): MI355LZ4_LINKED_RUNS,
- * MI355LZ4_LINKED_TWIN (0 = never, 1 = always), MI355LZ4_LINKED_TWIN_PIECE,
+ * MI355LZ4_LINKED_RUNIN (0 = never, 1 = always), MI355LZ4_LINKED_RUNIN_PIECE,
+ * MI355LZ4_LINKED_RUNIN_BLOCKS,
  * MI355LZ4_LINKED_PTR, MI355LZ4_LINKED_PTR_BLOCKS, MI355LZ4_LINKED_POOL_BLOCKS.
  * replaces: decompressChunk, Internal/LZ4.hs:291-336. */
 int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,

@@ -18,7 +18,7 @@ names = {"bench_roundtrip.json": "bench_roundtrip.json", "bench_random256k.json"
          "linked_async_cost.txt": "linked_async_cost.txt", "linked_single_stream_kernel_stats.csv": "linked_single_stream_kernel_stats.csv", "bench_one_stream_rehearsal.jsonl": "bench_one_stream_rehearsal.jsonl", "realtext_ratio.txt": "realtext_ratio.txt", "size_vs_reference.txt": "size_vs_reference.txt",
          "host_api_rate.jsonl": "host_api_rate.jsonl", "valu_issue_rate.txt": "valu_issue_rate.txt",
          "bench_n2_selflaunch_rehearsal.json": "bench_n2_selflaunch_rehearsal.json", "linked_streams_rate.jsonl": "linked_streams_rate.jsonl", "kernel_resources.txt": "kernel_resources.txt",
-         "bench_roundtrip_8GiB.json": "bench_roundtrip_8GiB.json", "linked_twin_decode.txt": "linked_twin_decode.txt"}
+         "bench_roundtrip_8GiB.json": "bench_roundtrip_8GiB.json", "linked_runin_decode.txt": "linked_runin_decode.txt"}
 files = []
 for src, dst in names.items():
     p = os.path.join(E, src)

@@ -1,6 +1,7 @@
-"""Development aid: ONE reference-written linked stream (oracle compressor on the host), decoded by the GPU with the twin
-decode off / on and different piece lengths; every output is compared with the input.
-usage: linked_twin_time.py [kind=text] [blocks=16384] [block_len=65536]"""
+"""Development aid: ONE reference-written linked stream (oracle compressor on the host), decoded by the GPU with the run-in
+decode off / on and different run-in and piece lengths (RUNIN_CFGS="blocks of run-in:blocks per piece,...", 0 = default);
+every output is compared with the input.
+usage: linked_runin_time.py [kind=text] [blocks=16384] [block_len=65536]"""
 import os, sys, struct, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "streamly-lz4_amd"))
@@ -12,7 +13,7 @@ bl = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 O = Oracle(); eng = S.Engine(0); dev = torch.device("cuda:0")
 t0 = time.time()
 # a few hundred distinct blocks cycled with a stride keep the host compression short; the stream is still one linked stream
-base_n = nb if os.environ.get("TWIN_DISTINCT") else min(nb, 2048)
+base_n = nb if os.environ.get("RUNIN_DISTINCT") else min(nb, 2048)
 data = O.gen(kind, base_n, bl, first_block=7).tobytes()
 data = (data * ((nb + base_n - 1) // base_n))[: nb * bl]
 fr = O.frame_compress(data, bl, 1, 8, True)
@@ -27,12 +28,18 @@ ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
 src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
 out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev); res = torch.zeros(nb, dtype=torch.int32, device=dev)
 e0, e1 = S.Event(), S.Event()
-pieces = [int(x) for x in os.environ.get("TWIN_PIECES", "4,8,12,16").split(",")]
-configs = [("pointer pass", {"MI355LZ4_LINKED_TWIN": "0"})] + [("twin, pieces of %d" % b, {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": str(b)}) for b in pieces] + [("default", {})]
+runins = [x.split(":") for x in os.environ.get("RUNIN_CFGS", "").split(",") if x]      # "blocks of run-in:blocks per piece" (0 = default)
+configs = [("pointer pass", {"MI355LZ4_LINKED_RUNIN": "0"})]
+for w, b in runins:
+    env = {"MI355LZ4_LINKED_RUNIN": "1"}
+    if int(w): env["MI355LZ4_LINKED_RUNIN_BLOCKS"] = w
+    if int(b): env["MI355LZ4_LINKED_RUNIN_PIECE"] = b
+    configs.append(("run-in %s, pieces of %s" % (w, b), env))
+configs.append(("default", {}))
 for label, env in configs:
-    if os.environ.get("TWIN_ONLY") and os.environ["TWIN_ONLY"] not in label:
+    if os.environ.get("RUNIN_ONLY") and os.environ["RUNIN_ONLY"] not in label:
         continue
-    for k in ("MI355LZ4_LINKED_TWIN", "MI355LZ4_LINKED_TWIN_PIECE"):
+    for k in ("MI355LZ4_LINKED_RUNIN", "MI355LZ4_LINKED_RUNIN_BLOCKS", "MI355LZ4_LINKED_RUNIN_PIECE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     best = 1e9
@@ -41,4 +48,4 @@ for label, env in configs:
         eng.record(e0); eng.decompress_batch_device(buf, len(fr), off, nb, out, ooff, res, linked=True); eng.record(e1); eng.synchronize()
         best = min(best, eng.elapsed_ms(e0, e1))
     ok = bool((res == bl).all().item()) and torch.equal(out, src)
-    print("  %-20s %8.3f ms  %7.1f GB/s  %s" % (label, best, nb * bl / best / 1e6, "ok" if ok else "MISMATCH"), flush=True)
+    print("  %-26s %8.3f ms  %7.1f GB/s  %s" % (label, best, nb * bl / best / 1e6, "ok" if ok else "MISMATCH"), flush=True)

@@ -30,8 +30,10 @@ for N in 2 3; do
       bench.py --gpus $N --steps 5 --warmup 1 --workload text --one-stream --blocks 2048 2>/dev/null | grep '^{' >> "$E/bench_one_stream_rehearsal.jsonl"
 done
 ( cd /tmp && export TMPDIR=/tmp && rm -rf "$E/linked_prof" && rocprofv3 --kernel-trace --stats --output-format csv -d "$E/linked_prof" -- python3 "$R/scripts/prof_linked.py" 4096 5 > "$E/linked_prof.log" 2>&1; cp "$E"/linked_prof/*/*kernel_stats.csv "$E/linked_single_stream_kernel_stats.csv" 2>/dev/null )
-# one reference-written linked text stream of 1, 2 and 4 GiB: pointer pass against twin decode
-for nb in 16384 32768 65536; do TWIN_PIECES=12,16 python3 scripts/linked_twin_time.py text $nb 2>/dev/null | grep -v amdgpu; done > "$E/linked_twin_decode.txt"
+# one reference-written linked text stream of 1, 2 and 4 GiB (and 1 GiB in blocks of 256 KiB and 1 MiB): pointer pass against run-in decode
+{ for nb in 16384 32768 65536; do RUNIN_CFGS=9:0,13:0 python3 scripts/linked_runin_time.py text $nb 2>/dev/null | grep -v amdgpu; done
+  python3 scripts/linked_runin_time.py text 4096 262144 2>/dev/null | grep -v amdgpu
+  python3 scripts/linked_runin_time.py text 1024 1048576 2>/dev/null | grep -v amdgpu; } > "$E/linked_runin_decode.txt"
 python3 scripts/linked_async_cost.py 2>/dev/null | grep blocks > "$E/linked_async_cost.txt"
 python3 scripts/realtext_ratio.py 2>/dev/null | grep input > "$E/realtext_ratio.txt"
 python3 scripts/size_vs_ref.py 2>/dev/null | grep segs > "$E/size_vs_reference.txt"

@@ -55,10 +55,11 @@ while time.time() - t0 < budget:
             out, blen = eng.decompress_batch(comp_gpu)
             assert out == data, ("gpu stream", dv, bl, nb, lit_max, off_max, mlen_max, accel, cases)
     eng.set_decoder(0)
-    # the reference's linked stream through the linked decode (default path, run walker, pointer pass, twin decode with random piece lengths)
+    # the reference's linked stream through the linked decode (default path, run walker, pointer pass, run-in decode with random piece and run-in lengths)
     fr_l = o.frame_compress(data, bl, accel, 8, True)
     for env in ({}, {"MI355LZ4_LINKED_RUNS": "100000"}, {"MI355LZ4_LINKED_RUNS": "0"},
-                {"MI355LZ4_LINKED_RUNS": "0", "MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": str(rng.choice([1, 2, 3, 16]))}):
+                {"MI355LZ4_LINKED_RUNS": "0", "MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNIN_PIECE": str(rng.choice([1, 2, 3, 16])),
+                 "MI355LZ4_LINKED_RUNIN_BLOCKS": str(rng.choice([1, 2, 11]))}):
         for k, v in env.items():
             os.environ[k] = v
         out, blen = eng.decompress_batch(fr_l, linked=True)

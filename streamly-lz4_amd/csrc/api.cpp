@@ -613,6 +613,14 @@ static int linked_finish(mi355lz4_ctx *c)
     return check_launch("decode launch");
 }
 
+// run-in decode of long linked streams: blocks of 64 KiB of run-in, and the span (in 64 KiB) from which it is the default
+#ifndef RUNIN_DEFAULT_64K
+#define RUNIN_DEFAULT_64K 11
+#endif
+#ifndef RUNIN_MIN_SPAN
+#define RUNIN_MIN_SPAN 10240
+#endif
+#define RUNIN_ROUNDS 8          // launches of pieces to be redone before the call is left to the pointer pass
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
@@ -637,7 +645,9 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
-    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.twin = nullptr; a.twinStride = 0; a.seamPages = nullptr; a.twinPiece = 0; a.twinSpin = 0; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
+    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
+    a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
     int r;
     if (linked) {
@@ -707,72 +717,74 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         }
     }
     // Long runs of dependent blocks -- a stream written by the reference's compressor is ONE such run -- in pieces of
-    // consecutive blocks, every piece decoded twice with two stand-ins for its missing dictionary; what differs is what is
-    // not final yet, and that decays to nothing within a piece (kernels.hip, "TWIN DECODE").  One byte of scratch per
-    // output byte of a segment (<= 2 GiB).  A piece is a serial chain of block decodes (0.45 ms each), so the path pays
-    // where the pieces fill the chip anyway: spans of 12 288 blocks and more (measured on text, 64 KiB blocks: 16 384
-    // blocks 12.5 against 16.2 ms for the pointer pass; 4 096 blocks would take 10 against 4.5 ms).
-    // MI355LZ4_LINKED_TWIN: 0 = never, 1 = whenever it applies (the tests); MI355LZ4_LINKED_TWIN_PIECE: blocks per
-    // piece (default 14 below 20 480 blocks, 16 above: with fewer the taint reaches a piece's last block often enough to
-    // chain the pieces' second halves -- 1 GiB of text, 16 384 distinct blocks: 15.8 ms with 10, 14.3 with 12, 12.1 with 14,
-    // 12.5 with 16, 13.7 with 20; 4 GiB: 80 ms with 8, 41 with 12, 32 with 16).
+    // consecutive blocks, every piece decoded from a few blocks in front of it ("run-in": by the time the wave reaches
+    // the piece the dictionary it carries is the true one; checked against what the piece in front wrote, redone where it
+    // is not: kernels.hip, "RUN-IN DECODE").  A call's serial chain is run-in + piece blocks (0.45 ms per 64 KiB), one
+    // wave per piece, a ring of two blocks of scratch per piece.
+    // MI355LZ4_LINKED_RUNIN: 0 = never, 1 = whenever it applies (the tests); MI355LZ4_LINKED_RUNIN_BLOCKS: blocks of
+    // run-in; MI355LZ4_LINKED_RUNIN_PIECE: blocks per piece (default: as many as give every piece a wave slot of its own).
     {
-        const char *envTwin = getenv("MI355LZ4_LINKED_TWIN"), *envPiece = getenv("MI355LZ4_LINKED_TWIN_PIECE");
+        const char *envRun = getenv("MI355LZ4_LINKED_RUNIN"), *envPiece = getenv("MI355LZ4_LINKED_RUNIN_PIECE"),
+                   *envBlocks = getenv("MI355LZ4_LINKED_RUNIN_BLOCKS");
         const bool plain = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS");
         const int span0 = last - first + 1;
-        const bool useTwin = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
-                             (envTwin ? atoi(envTwin) != 0 : (plain && span0 >= 12288));
-        if (useTwin) {
-            const uint64_t stride = (((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u) * 65536u;
-            const int piece = (envPiece && atoi(envPiece) > 0) ? atoi(envPiece) : (span0 < 20480 ? 14 : 16);
-            // a piece's wave polls for the piece in front for up to ~20 ms (s_sleep 64 = 4096 cycles a poll) as long as every
-            // piece of the launch has a wave slot of its own (256 CUs x 8 waves at least): no wave waits for one not yet started
-            const char *envSpin = getenv("MI355LZ4_LINKED_TWIN_SPIN");
-            a.twinSpin = envSpin ? atoi(envSpin) : 10000;
-            int segBlocks = (int)(((uint64_t)1 << 31) / stride);
-            segBlocks = segBlocks / piece * piece;
-            if (segBlocks < piece) segBlocks = piece;
-            if (segBlocks > span0) segBlocks = (span0 + piece - 1) / piece * piece;
-            const size_t nPiecesMax = (size_t)segBlocks / piece + 1;
-            const size_t metaBytes = 131072 + (size_t)segBlocks * 12 + (2 + nPiecesMax) * 4 + 64;
+        const uint64_t per64 = ((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u;
+        const uint64_t stride = per64 * 65536u;
+        const bool useRunIn = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
+                              (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= RUNIN_MIN_SPAN));
+        if (useRunIn) {
+            // the taint of a missing dictionary is gone after 6 to 11 blocks of 64 KiB on text (scripts/runin_sim.py)
+            // (64 KiB blocks: the 6th to 12th block is the first exact one; bigger blocks carry it further in bytes -- 256 KiB: 4
+            // blocks, 1 MiB: 2, measured)
+            int runIn = (envBlocks && atoi(envBlocks) > 0) ? atoi(envBlocks)
+                        : (per64 == 1 ? RUNIN_DEFAULT_64K : (int)((RUNIN_DEFAULT_64K + per64) / per64) + 1);
+            if (runIn > 64) runIn = 64;
+            // pieces: one wave slot each (256 CUs x 16 waves), and at most 2 GiB of rings
+            uint64_t maxPieces = ((uint64_t)1 << 31) / (2u * stride);
+            if (maxPieces < 1) maxPieces = 1;
+            if (maxPieces > 4096) maxPieces = 4096;
+            int piece = (int)(((uint64_t)span0 + maxPieces - 1) / maxPieces);
+            if (envPiece && atoi(envPiece) > 0) piece = atoi(envPiece);
+            if (piece < 1) piece = 1;
+            const char *envSpin = getenv("MI355LZ4_LINKED_RUNIN_SPIN");
+            a.runSpin = envSpin ? atoi(envSpin) : 10000;
+            int segBlocks = (int)((maxPieces * (uint64_t)piece < (uint64_t)span0) ? maxPieces * (uint64_t)piece : (uint64_t)span0);
+            const size_t nPiecesMax = ((size_t)segBlocks + piece - 1) / piece;
+            const size_t metaBytes = 65536 + (size_t)segBlocks * 4 + nPiecesMax * 20 + 64;
             bool done = false;
-            if (dev_reserve(c->ptrBuf, (size_t)segBlocks * stride) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0) {
+            if (dev_reserve(c->ptrBuf, nPiecesMax * 2u * stride) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0) {
                 uint8_t *meta = (uint8_t *)c->tolMeta.p;
-                a.seamPages = meta; a.twin = (uint8_t *)c->ptrBuf.p; a.twinStride = stride; a.twinPiece = piece;
-                a.twinRes = (int32_t *)(meta + 131072); a.twinTaint = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 4);
-                a.twinCtl = (uint32_t *)(meta + 131072 + (size_t)segBlocks * 12);
-                // the first pass's results of the segment, kept: a segment that does not finish this way gets them back (a piece
-                // is only right if every piece in front of it is -- which dictionary is in force behind a block that fails
-                // depends on that failure -- so a segment with a broken block keeps nothing of what its pieces concluded)
-                int32_t *snap = (int32_t *)(meta + 131072 + (size_t)segBlocks * 8);
+                a.zeroPage = meta; a.ring = (uint8_t *)c->ptrBuf.p; a.ringStride = stride; a.runPiece = piece; a.runIn = runIn;
+                a.runRes = (int32_t *)(meta + 65536);
+                a.runInfo = (int32_t *)(meta + 65536 + (size_t)segBlocks * 4);
+                a.runDirty = (uint32_t *)(meta + 65536 + (size_t)segBlocks * 4 + nPiecesMax * 16);
+                a.runCtl = (uint32_t *)(meta + 65536 + (size_t)segBlocks * 4 + nPiecesMax * 20);
                 HIP_TRY(hipMemsetAsync(meta, 0x00, 65536, c->stream));
-                HIP_TRY(hipMemsetAsync(meta + 65536, 0xff, 65536, c->stream));
                 done = true;
                 for (int s0 = first; s0 <= last && done; s0 += segBlocks) {
                     a.segFirst = s0; a.segEnd = (s0 + segBlocks < last + 1) ? s0 + segBlocks : last + 1;
-                    if ((a.segEnd - a.segFirst + piece - 1) / piece > 2048) a.twinSpin = 0;
-                    HIP_TRY(hipMemcpyAsync(snap, result + a.segFirst, (size_t)(a.segEnd - a.segFirst) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-                    HIP_TRY(hipMemsetAsync(a.twinCtl, 0, 8, c->stream));
-                    launch_twin_decode(a, c->stream);
+                    HIP_TRY(hipMemsetAsync(a.runCtl, 0, 8, c->stream));
+                    launch_runin_decode(a, c->stream);
                     bool segDone = false;
-                    for (int round = 0; round < 64 && !segDone; round++) {
-                        launch_twin_fix(a, c->stream);
-                        HIP_TRY(hipMemcpyAsync(stat, a.twinCtl, 8, hipMemcpyDeviceToHost, c->stream));
+                    for (int round = 0; round < RUNIN_ROUNDS && !segDone; round++) {
+                        a.runRound = round;
+                        if (round) HIP_TRY(hipMemsetAsync(a.runCtl, 0, 4, c->stream));
+                        launch_runin_fix(a, c->stream);
+                        HIP_TRY(hipMemcpyAsync(stat, a.runCtl, 8, hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(hipStreamSynchronize(c->stream));
-                        if (stat[1] != 0) break;                 // a block failed with its true dictionary
+                        if (stat[1] != 0) break;                 // a block failed with the dictionary it got
                         segDone = stat[0] == 0;
                     }
                     done = segDone;
-                    if (!segDone)
-                        HIP_TRY(hipMemcpyAsync(result + a.segFirst, snap, (size_t)(a.segEnd - a.segFirst) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+                    if (segDone) launch_runin_publish(a, c->stream);
                 }
             }
             (void)hipGetLastError();
+            a.ring = nullptr; a.zeroPage = nullptr; a.runRes = nullptr; a.runCtl = nullptr; a.runInfo = nullptr; a.runDirty = nullptr;
+            a.runPiece = 0; a.runIn = 0;
             if (done) { link_scratch_release(c); return check_launch("decode launch"); }
-            // Not finished this way (a broken block, pieces that never become final, no scratch): the segments that did finish
-            // are final, the one that did not has its first-pass results back; the blocks that carry the first pass's codec
-            // error go through the pointer / serial pass below
-            a.twin = nullptr; a.seamPages = nullptr; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
+            // Not finished this way (a broken block, rounds that run out, no scratch): the segments that did finish are final,
+            // the one that did not has the first pass's results still; its blocks go through the passes below
             a.segFirst = 0; a.segEnd = nBlocks;
             HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
             HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
@@ -1694,7 +1706,9 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.streamFirst = nullptr; a.nStreams = 0; a.lookBack = 0;
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
-    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.twin = nullptr; a.twinStride = 0; a.seamPages = nullptr; a.twinPiece = 0; a.twinSpin = 0; a.twinRes = nullptr; a.twinTaint = nullptr; a.twinCtl = nullptr;
+    a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
+    a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     if (s->dictLen) {
         // the exact decoder with the dictionary in force, at once (a block that does not reach back decodes the same)
         if (hipMemcpyAsync(resDev, (const uint8_t *)s->inDev.p + 16, 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return -1;

@@ -52,15 +52,18 @@ struct DecodeArgs {
     // runList[1..] = first block of each run, at most runCap of them; null: the launch covers one run that starts at segFirst
     int32_t *runList;
     int runCap;
-    // long linked streams, twin decode (kernels.hip, k_twin_*): pieces of twinPiece consecutive blocks of [segFirst, segEnd)
-    uint8_t *twin;                // the second decode's output: block f at twin + (f - segFirst) * twinStride
-    uint64_t twinStride;
-    const uint8_t *seamPages;     // 2 x 64 KiB: all 0x00, all 0xFF -- the two stand-ins for a piece's missing dictionary
-    int twinPiece;                // blocks per piece
-    int twinSpin;                 // k_twin_fix: how many times a piece polls for the piece in front of it before it leaves itself to the next launch
-    int32_t *twinRes;             // per block of the segment: the first pass's result with the stand-in (sizes do not depend on it)
-    uint32_t *twinTaint;          // per block of the segment: bytes that differ between the two decodes (0: the block is final)
-    uint32_t *twinCtl;            // [0] pieces not final yet, [1] a block failed with its true dictionary (caller falls back), [2 + p] piece p final
+    // long linked streams, run-in decode (kernels.hip, k_runin_*): pieces of runPiece consecutive blocks of [segFirst, segEnd)
+    uint8_t *ring;                // scratch: two blocks per piece (piece p at ring + p * 2 * ringStride)
+    uint64_t ringStride;          // >= the largest block capacity
+    const uint8_t *zeroPage;      // 64 KiB of 0x00: the stand-in for the dictionary of the block a run-in starts at
+    int runPiece;                 // blocks per piece
+    int runIn;                    // blocks a piece decodes in front of its own (<= 64)
+    int runSpin;                  // k_runin_fix: how many times a piece polls for the piece in front of it before it leaves itself to the next round
+    int runRound;                 // k_runin_fix: the round this launch is
+    int32_t *runRes;              // per block of the segment: its result (result[] is written when everything is final)
+    int32_t *runInfo;             // per piece {block the run-in's dictionary came from | -1 | -2 exact, its length, its ring slot, -}
+    uint32_t *runDirty;           // per piece: the round in which it is to be redone, 0xffffffff = none
+    uint32_t *runCtl;             // [0] pieces marked for the next round, [1] give the call up (1: a block failed, 2: a chain of dirty pieces)
     // experiment builds only (MI355LZ4_EXPERIMENTS; decode_par.hpp, LIST): block blk's token list lives at tokList +
     // blockOff[blk] / 2 (a sequence is at least three compressed bytes), tokCnt[blk] entries; both null without the list pass
     uint8_t *tokList;
@@ -110,8 +113,9 @@ void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: th
 size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
 void launch_link_stat(const DecodeArgs &a, hipStream_t s);       // linkStat from result[] (the decode launchers call it themselves)
-void launch_twin_decode(const DecodeArgs &a, hipStream_t s);     // long linked stream: both decodes of every piece + the comparison
-void launch_twin_fix(const DecodeArgs &a, hipStream_t s);        // ... one round of pieces whose dictionary has become final
+void launch_runin_decode(const DecodeArgs &a, hipStream_t s);    // long linked stream: every piece with its run-in + the comparison
+void launch_runin_fix(const DecodeArgs &a, hipStream_t s);       // ... one round (a.runRound) of pieces to be redone
+void launch_runin_publish(const DecodeArgs &a, hipStream_t s);   // ... results into result[]
 void launch_linked_runs(const DecodeArgs &a, hipStream_t s);      // one stream, short runs of dependent blocks: one wave per run, exact decoder with dictionary
 size_t ptr_ctl_bytes();
 size_t tol_region_bytes();

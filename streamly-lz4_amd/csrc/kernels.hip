@@ -704,34 +704,8 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Long linked streams: TWIN DECODE (round 5).  In a stream written by the reference's compressor every block needs the
-// block before it, but not much of it: on text a third of a block's bytes derive -- through chains of matches -- from
-// the previous block, 5 % from the one before that, 1 % from the third, and after about eight blocks nothing is left
-// (scripts/tol_taint_sim.py; byte-exact -- tracked per match, as the tolerant pass has to, the dependent share stays at
-// 76 % in every block, which is why that pass hands practically the whole stream to the pointer machinery).  So the
-// stream is cut into PIECES of consecutive blocks and one wavefront decodes a piece in order with the ordinary
-// lane-parallel decoder, every block with the block before it as its dictionary -- only the piece's first block lacks
-// its own.  It gets a stand-in, and the piece is decoded TWICE (two waves, side by side): once with 64 KiB of 0x00 in
-// the dictionary's place and once with 64 KiB of 0xFF.  A byte that derives from the missing dictionary, by whatever
-// chain, is a copy of one of its bytes and comes out 0x00 in one decode and 0xFF in the other; every other byte is the
-// same in both.  Comparing the two outputs therefore marks, exactly, the bytes that are not final -- no taint logic in
-// the decoder, no lists, no pointers; one byte of scratch per output byte.  A block's SIZE and result code depend on
-// its tokens only, so they are known after this pass.
-//   Then the pieces are finished front to back where it matters: a piece whose predecessor's last block is final
-// (no differing byte: the normal case with eight blocks per piece) re-decodes its leading blocks with the true
-// dictionary until it reaches a block without a differing byte; pieces whose predecessor is not final yet wait for the
-// next round (k_twin_fix is launched until a counter says that no piece is left).  Anything unusual -- a block that
-// fails with its true dictionary, too many rounds -- gives the segment's blocks the first pass's results back (a piece is
-// only right if every piece in front of it is: which dictionary is in force behind a failed block depends on the failure)
-// and the caller continues with the pointer pass, which treats what is final as final.
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool twin_true_dict(const DecodeArgs &a, int b0)
-{
-    // the block in front of the piece decoded in the first (standalone) pass: its output is the piece's real dictionary
-    return b0 == a.segFirst ? true : uni(a.result[b0 - 1]) > 0;
-}
-__device__ __forceinline__ void twin_dict_before(const DecodeArgs &a, int b0, const uint8_t *&dict, uint32_t &dictLen)
+// the dictionary in force in front of block b0 as the first pass's results have it (blocks in front of a segment are final)
+__device__ __forceinline__ void dict_before(const DecodeArgs &a, int b0, const uint8_t *&dict, uint32_t &dictLen)
 {
     dict = nullptr; dictLen = 0;
     if (a.dict0) { dict = a.dict0; dictLen = a.dict0Len; }
@@ -743,180 +717,276 @@ __device__ __forceinline__ void twin_dict_before(const DecodeArgs &a, int b0, co
 
 // (a piece is a serial chain of block decodes: what counts is one wave's speed, and the dictionary form of the decoder
 // spills at the 96 registers that five waves per SIMD allow -- these kernels take 128)
-#ifndef TWIN_WAVES
-#define TWIN_WAVES 4
+#ifndef RUNIN_WAVES
+#define RUNIN_WAVES 4
 #endif
-#define TWIN_OCC __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TWIN_WAVES, TWIN_WAVES)))
-// grid: 2 waves per piece (blockIdx & 1: 0 = the decode into the caller's buffer, stand-in 0x00; 1 = the twin, 0xFF)
-__global__ TWIN_OCC void k_twin_decode(DecodeArgs a)
+#define RUNIN_OCC __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNIN_WAVES, RUNIN_WAVES)))
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long linked streams: RUN-IN DECODE (round 5).  In a stream written by the reference's compressor every block needs the
+// block before it, but not much of it: on text a third of a block's bytes derive -- through chains of matches -- from
+// the previous block, 5 % from the one before that, 1 % from the third, and the 6th to 12th block is the first that has
+// no such byte left (scripts/runin_sim.py, byte-exact; tracked per MATCH, as the tolerant pass has to, the dependent share
+// stays at 76 % in every block, which is why that pass hands practically the whole stream to the pointer machinery).
+// So the stream is cut into PIECES of consecutive blocks, one wavefront per piece, and a piece does not start at its
+// first block but runIn blocks in front of it, with 64 KiB of zeros as the dictionary of the block it starts at; it
+// decodes those blocks with the ordinary lane-parallel decoder, every block with the one before it as its dictionary,
+// into a two-block ring of scratch, and by the time it reaches its own blocks the dictionary it carries is, as a rule,
+// the true one.  Whether it is needs no second decode: the block in front of a piece is decoded twice anyway -- by the
+// piece in front (into the caller's buffer) and by this piece's run-in (into the ring) -- and k_runin_verify compares
+// the two.  If they are equal, the piece's blocks are what the piece in front's last block makes of them, and by
+// induction from the first piece (which has its true dictionary) the whole stream is exact.  A call's serial chain is
+// runIn + piece blocks.  (The first half of round 5 decoded every piece TWICE, with 0x00 and 0xFF as stand-ins, and
+// re-decoded what differed: exact as well, but a chain of piece + the longest re-decoded prefix with two waves per
+// piece -- 1 GiB of text 12.5 ms against 10.1, 4 GiB 30.6 against 16.6.)
+//   A piece whose run-in did not arrive at the true dictionary is DIRTY: k_runin_fix decodes its blocks again, in
+// order, from the final dictionary, each into the ring first; a block that comes out as it was ends the work (all that
+// follows depends on it alone), a piece that changes up to its last block marks the piece behind it dirty for the next
+// round.  runDirty[p] holds the ROUND in which piece p is to be redone (RUNIN_CLEAN: none); a dirty piece behind a dirty
+// piece waits for it inside the launch (bounded), the host launches rounds until none is marked.  result[] is not
+// written before everything is final (k_runin_publish), so a call that gives up -- a block that fails with its
+// dictionary, too many dirty pieces in a row, rounds that run out -- leaves the first pass's results as they were for
+// the pointer pass.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RUNIN_CLEAN 0xffffffffu
+#ifndef RUNIN_CHAIN
+#define RUNIN_CHAIN 4
+#endif
+#define RUNIN_EXACT (-2)
+// the dictionary in force in front of block b0 once the blocks in front of it are final in out[] (their sizes in
+// result[] -- the first pass -- or runRes[])
+__device__ __forceinline__ void runin_dict_before(const DecodeArgs &a, int b0, const uint8_t *&dict, uint32_t &dictLen)
 {
-    __shared__ ParLds lds;
-    const int which = (int)(blockIdx.x & 1u), piece = (int)(blockIdx.x >> 1);
-    const int b0 = a.segFirst + piece * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
-    if (b0 >= b1) return;
-    const bool trueDict = twin_true_dict(a, b0);
-    if (trueDict && which) return;                               // nothing is missing: one decode, and it is final
-    const uint8_t *dict; uint32_t dictLen;
-    if (trueDict) twin_dict_before(a, b0, dict, dictLen);
-    else { dict = a.seamPages + (which ? 65536 : 0); dictLen = 65536u; }
-    for (int f = b0; f < b1; f++) {
-        const int r0 = uni(a.result[f]);                         // the standalone pass's result: nobody writes it in this launch
-        uint8_t *real = a.out + a.outOff[f];
-        if (r0 > 0) { dict = real; dictLen = (uint32_t)r0; if (!which && lane_id() == 0) a.twinRes[f - a.segFirst] = r0; continue; }
-        int r = r0;
-        uint8_t *dst = which ? a.twin + (uint64_t)(f - a.segFirst) * a.twinStride : real;
-        if (is_codec_error(r0) && dictLen > 0) {
-            const uint8_t *data = nullptr;
-            int compLen = 0, cap = 0;
-            r = read_block_header(a, f, data, compLen, cap);
-            if (r == 0 && (uint64_t)cap > a.twinStride) r = -1;  // (cannot happen: the stride is the largest capacity)
-            if (r == 0)
-                r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
-            r = uni(r);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        }
-        if (!which && lane_id() == 0) a.twinRes[f - a.segFirst] = r;
-        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }         // :2331-2333, :2353-2355: an empty or failed block leaves the dictionary
+    for (int j = b0 - 1; j >= a.segFirst; j--) {
+        const int r0 = uni(a.result[j]);
+        const int rj = r0 > 0 ? r0 : uni(a.runRes[j - a.segFirst]);
+        if (rj > 0) { dict = a.out + a.outOff[j]; dictLen = (uint32_t)rj; return; }
     }
+    dict_before(a, a.segFirst, dict, dictLen);
 }
 
-// one workgroup per block: how many bytes differ between the two decodes
-__global__ __launch_bounds__(256) void k_twin_compare(DecodeArgs a)
-{
-    const int f = a.segFirst + (int)blockIdx.x;
-    const int b0 = a.segFirst + ((f - a.segFirst) / a.twinPiece) * a.twinPiece;
-    const int r0 = a.result[f], r = a.twinRes[f - a.segFirst];
-    __shared__ uint32_t cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    if (!twin_true_dict(a, b0) && r0 <= 0 && r > 0) {
-        const uint8_t *x = a.out + a.outOff[f], *y = a.twin + (uint64_t)(f - a.segFirst) * a.twinStride;
-        for (int i = (int)threadIdx.x * 16; i < r; i += 256 * 16) {
-            if (i + 16 <= r && (((uintptr_t)(x + i)) & 15u) == 0) {
-                const uint4 u = *(const uint4 *)(x + i), v = *(const uint4 *)(y + i);
-                mine += (uint32_t)((u.x != v.x) + (u.y != v.y) + (u.z != v.z) + (u.w != v.w));
-            } else {
-                for (int k = i; k < min(i + 16, r); k++) mine += (uint32_t)(x[k] != y[k]);
-            }
-        }
-    }
-    if (mine) atomicAdd(&cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) a.twinTaint[f - a.segFirst] = cnt;
-}
-
-// pieces left to finish = those decoded with a stand-in; the others are final as they are
-__global__ __launch_bounds__(256) void k_twin_begin(DecodeArgs a)
-{
-    const int nPieces = (a.segEnd - a.segFirst + a.twinPiece - 1) / a.twinPiece;
-    const int p = (int)(blockIdx.x * 256u + threadIdx.x);
-    if (p >= nPieces) return;
-    const int b0 = a.segFirst + p * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
-    // (one THREAD per piece here: not twin_true_dict, whose answer is made wave-uniform for the kernels that run a wave per piece)
-    if (b0 == a.segFirst || a.result[b0 - 1] > 0) {
-        a.twinCtl[2 + p] = 2u;                                   // final; its results are published by k_twin_publish
-    } else {
-        a.twinCtl[2 + p] = 0u;
-        atomicAdd(&a.twinCtl[0], 1u);
-    }
-    (void)b1;
-}
-// (a launch of its own: k_twin_begin reads result[b0 - 1] of every piece, this one overwrites results)
-__global__ __launch_bounds__(256) void k_twin_publish(DecodeArgs a)
-{
-    const int f = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
-    if (f >= a.segEnd) return;
-    const int p = (f - a.segFirst) / a.twinPiece;
-    if (a.twinCtl[2 + p] == 2u) {
-        const int r = a.twinRes[f - a.segFirst];
-        if (a.result[f] <= 0) a.result[f] = r;
-        if (r < 0 && is_codec_error(r)) atomicOr(&a.twinCtl[1], 1u);      // failed with its true dictionary: the caller's other path reports it
-    }
-}
-
-// one wave per piece: finish it if the piece in front is final
-__global__ TWIN_OCC void k_twin_fix(DecodeArgs a)
+// one wave per piece
+__global__ RUNIN_OCC void k_runin_decode(DecodeArgs a)
 {
     __shared__ ParLds lds;
     const int p = (int)blockIdx.x;
-    const int b0 = a.segFirst + p * a.twinPiece, b1 = min(b0 + a.twinPiece, a.segEnd);
-    if (b0 >= b1 || uni((int)a.twinCtl[2 + p]) != 0) return;                          // final already
-    // The piece's dictionary is the block in front of it.  That block is final when its piece is, or -- the normal case --
-    // when the first pass already left no differing byte in it: the taint has died out before the piece's end.
+    const int b0 = a.segFirst + p * a.runPiece, b1 = min(b0 + a.runPiece, a.segEnd);
+    if (b0 >= b1) return;
+    // where the run-in starts: runIn blocks back, or behind the last block in that range that decoded on its own
+    int w0 = max(b0 - a.runIn, a.segFirst);
+    bool exact = w0 == a.segFirst;
     const uint8_t *dict = nullptr; uint32_t dictLen = 0;
     {
-        const int j = b0 - 1 - a.segFirst;                       // (p > 0 here: piece 0 has its true dictionary and is never pending)
-        const int rj = uni(a.twinRes[j]);
-        const bool clean = rj > 0 && uni(a.result[b0 - 1]) <= 0 && uni((int)a.twinTaint[j]) == 0;
-        bool prevFinal = uni((int)__hip_atomic_load(&a.twinCtl[2 + p - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-        // Not ready: the piece in front is being finished by a wave of this launch (they are dispatched in order: it is
-        // resident whenever this one is).  Wait for it a bounded while -- a wait that gives up is a piece left for the next
-        // launch, never a wave that cannot end.
-        for (int spin = 0; !clean && !prevFinal && spin < a.twinSpin; spin++) {
-            __builtin_amdgcn_s_sleep(64);
-            prevFinal = uni((int)__hip_atomic_load(&a.twinCtl[2 + p - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != 0;
-        }
-        if (!clean && !prevFinal) return;                        // next round
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        if (clean && !prevFinal) { dict = a.out + a.outOff[b0 - 1]; dictLen = (uint32_t)rj; }   // (its result is not published yet)
-        else twin_dict_before(a, b0, dict, dictLen);
+        const int j = b0 - 1 - lane_id();
+        const int rj = j >= w0 ? a.result[j] : 0;
+        const unsigned long long own = __ballot(rj > 0);
+        if (own) { w0 = b0 - (int)__builtin_ctzll(own); exact = true; }
     }
-    bool redo = true;                                            // blocks with differing bytes form a prefix of the piece
-    for (int f = b0; f < b1; f++) {
-        const int r0 = uni(a.result[f]);
-        uint8_t *dst = a.out + a.outOff[f];
-        int r = r0 > 0 ? r0 : uni(a.twinRes[f - a.segFirst]);
-        if (r0 <= 0) {
-            // (only a block that was decoded says anything about the bytes behind it: an empty or rejected block leaves the
-            // dictionary where it was)
-            if (redo && is_codec_error(r0) && r > 0 && uni((int)a.twinTaint[f - a.segFirst]) == 0) redo = false;
-            if (redo && is_codec_error(r0) && dictLen > 0) {
-                const uint8_t *data = nullptr;
-                int compLen = 0, cap = 0;
-                r = read_block_header(a, f, data, compLen, cap);
-                if (r == 0)
-                    r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
-                r = uni(r);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-            } else if (redo && is_codec_error(r0)) {
-                // No dictionary is in force (every block in front failed or was empty): what the stand-in made of this block
-                // does not count -- on its own the block fails, as the first pass found (:2331: a failed block leaves no
-                // dictionary behind)
-                r = r0;
-            }
-            if (r < 0 && is_codec_error(r)) {
-                // fails with its true dictionary: the stream is broken here.  The block keeps the standalone pass's result and
-                // the caller's pointer / serial path produces the reference's code and what follows from it (:2331, :2353)
-                if (lane_id() == 0) atomicOr(&a.twinCtl[1], 1u);
-                return;
-            }
-            if (lane_id() == 0) a.result[f] = r;
+    if (exact) runin_dict_before(a, w0, dict, dictLen);           // (blocks of the segment in front of w0: w0 - 1 decoded on its own, or there is none)
+    else { dict = a.zeroPage; dictLen = 65536u; }
+    uint8_t *ring = a.ring + (uint64_t)p * 2u * a.ringStride;
+    int dictBlk = -1;
+    for (int f = w0; f < b1; f++) {
+        const bool own = f >= b0;                                 // (in front of b0: the run-in; no block of it decoded on its own)
+        if (f == b0 && lane_id() == 0) {
+            int32_t *info = a.runInfo + 4 * p;
+            info[0] = exact ? RUNIN_EXACT : dictBlk;              // -1: the stand-in is still in force
+            info[1] = (int32_t)dictLen;
+            info[2] = dictBlk >= 0 ? ((dictBlk - w0) & 1) : 0;
         }
-        if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-    if (lane_id() == 0) {
-        __hip_atomic_store(&a.twinCtl[2 + p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        atomicSub(&a.twinCtl[0], 1u);
+        const int r0 = uni(a.result[f]);                          // the standalone pass's result: nobody writes it before k_runin_publish
+        uint8_t *dst = own ? a.out + a.outOff[f] : ring + (uint64_t)((f - w0) & 1) * a.ringStride;
+        int r = r0;
+        if (is_codec_error(r0) && dictLen > 0) {                  // (an empty or rejected block leaves the dictionary, :2331-2333)
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, f, data, compLen, cap);
+            if (r == 0 && !own && (uint64_t)cap > a.ringStride) r = -1;   // (cannot happen: the stride is the largest capacity)
+            if (r == 0)
+                r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
+            r = uni(r);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the next block reads this one through the vector cache
+        }
+        if (own && lane_id() == 0) {
+            a.runRes[f - a.segFirst] = r;
+            if (is_codec_error(r)) atomicOr(&a.runCtl[1], 1u);  // fails with the dictionary it got: the exact path decides what that means
+        }
+        if (r > 0) { dict = dst; dictLen = (uint32_t)r; dictBlk = f; }
     }
 }
 
-void launch_twin_decode(const DecodeArgs &a, hipStream_t s)
+// one workgroup per piece: is the dictionary the run-in arrived with the one the piece in front left?
+__global__ __launch_bounds__(256) void k_runin_verify(DecodeArgs a)
 {
-    const int n = a.segEnd - a.segFirst;
-    if (n <= 0) return;
-    const int nPieces = (n + a.twinPiece - 1) / a.twinPiece;
-    hipLaunchKernelGGL(k_twin_decode, dim3((unsigned)nPieces * 2u), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_twin_compare, dim3((unsigned)n), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_twin_begin, dim3((unsigned)((nPieces + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_twin_publish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    const int p = (int)blockIdx.x;
+    const int b0 = a.segFirst + p * a.runPiece;
+    const int32_t *info = a.runInfo + 4 * p;
+    __shared__ uint32_t diff;
+    __shared__ int sj, slen;
+    if (threadIdx.x == 0) {
+        diff = 0; sj = -1; slen = 0;
+        if (info[0] != RUNIN_EXACT) {
+            for (int j = b0 - 1; j >= a.segFirst; j--) {
+                const int r0 = a.result[j];
+                const int rj = r0 > 0 ? r0 : a.runRes[j - a.segFirst];
+                if (rj > 0) { sj = j; slen = rj; break; }
+            }
+            if (sj < 0 || sj != info[0] || slen != info[1]) diff = 1;
+        }
+    }
+    __syncthreads();
+    if (info[0] != RUNIN_EXACT && diff == 0) {
+        const uint8_t *x = a.out + a.outOff[sj];
+        const uint8_t *y = a.ring + ((uint64_t)p * 2u + (uint64_t)info[2]) * a.ringStride;
+        uint32_t mine = 0;
+        for (int i = (int)threadIdx.x * 16; i < slen; i += 256 * 16) {
+            if (i + 16 <= slen && (((uintptr_t)(x + i)) & 15u) == 0) {
+                const uint4 u = *(const uint4 *)(x + i), v = *(const uint4 *)(y + i);
+                mine |= (uint32_t)((u.x != v.x) | (u.y != v.y) | (u.z != v.z) | (u.w != v.w));
+            } else {
+                for (int k = i; k < min(i + 16, slen); k++) mine |= (uint32_t)(x[k] != y[k]);
+            }
+        }
+        if (mine) atomicOr(&diff, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.runDirty[p] = (info[0] != RUNIN_EXACT && diff) ? 0u : RUNIN_CLEAN;
 }
-void launch_twin_fix(const DecodeArgs &a, hipStream_t s)
+
+// dst[0, n) = src[0, n); returns whether that changed dst (whole wave; dst and src do not overlap)
+__device__ __forceinline__ bool wave_copy_changed(uint8_t *dst, const uint8_t *src, int n)
+{
+    uint32_t d = 0;
+    const int head = min(n, (int)((16u - (uint32_t)(uintptr_t)dst) & 15u));
+    if (lane_id() < head) { const uint8_t o = dst[lane_id()], v = src[lane_id()]; d |= (uint32_t)(o != v); dst[lane_id()] = v; }
+    const int body = (n - head) >> 4;
+    for (int i = lane_id(); i < body; i += LZ4_WAVE) {
+        uint4 o = *(const uint4 *)(dst + head + 16 * i), v;
+        __builtin_memcpy(&v, src + head + 16 * i, 16);
+        d |= (uint32_t)((o.x != v.x) | (o.y != v.y) | (o.z != v.z) | (o.w != v.w));
+        *(uint4 *)(dst + head + 16 * i) = v;
+    }
+    const int t0 = head + 16 * body;
+    if (t0 + lane_id() < n) { const uint8_t o = dst[t0 + lane_id()], v = src[t0 + lane_id()]; d |= (uint32_t)(o != v); dst[t0 + lane_id()] = v; }
+    return __ballot(d != 0) != 0ull;
+}
+
+// one wave per piece and round: redo a dirty piece from its final dictionary
+__global__ RUNIN_OCC void k_runin_fix(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int p = (int)blockIdx.x;
+    const uint32_t round = (uint32_t)a.runRound;
+    const int b0 = a.segFirst + p * a.runPiece, b1 = min(b0 + a.runPiece, a.segEnd);
+    if (b0 >= b1 || (uint32_t)uni((int)__hip_atomic_load(&a.runDirty[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != round) return;
+    // (p > 0: piece 0 starts at the segment's first block and is exact.)  The piece in front is being redone in this launch:
+    // wait for it -- waves are dispatched in order, it is resident whenever this one is -- a bounded while; a wait that
+    // gives up leaves the piece to the next round (the wave in front takes a piece marked for THIS round to be waiting for it)
+    // Pieces to be redone in a row are a serial chain, and a stream whose every block is made of the block before it (a
+    // 60 000-byte period of noise) has nothing but those: more than RUNIN_CHAIN in front of this one and the call is given up
+    // for the pointer pass, which resolves such chains in log steps.
+    {
+        int k = 1;
+        while (k <= RUNIN_CHAIN && p - k > 0 &&
+               (uint32_t)uni((int)__hip_atomic_load(&a.runDirty[p - k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == round) k++;
+        if (k > RUNIN_CHAIN) {
+            if (lane_id() == 0) {
+                atomicOr(&a.runCtl[1], 2u);
+                __hip_atomic_store(&a.runDirty[p], RUNIN_CLEAN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+    for (int spin = 0;; spin++) {
+        if ((uint32_t)uni((int)__hip_atomic_load(&a.runDirty[p - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != round) break;
+        if (spin >= a.runSpin) {
+            if (lane_id() == 0) {
+                __hip_atomic_store(&a.runDirty[p], round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&a.runCtl[0], 1u);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    const uint8_t *dict = nullptr; uint32_t dictLen = 0;
+    runin_dict_before(a, b0, dict, dictLen);
+    uint8_t *ring = a.ring + (uint64_t)p * 2u * a.ringStride;
+    bool changed = true;                                         // the dictionary in force differs from what the blocks were made with
+    for (int f = b0; f < b1 && changed; f++) {
+        const int r0 = uni(a.result[f]);
+        if (r0 > 0) { changed = false; break; }                  // decoded on its own: what follows depends on this block alone
+        if (!is_codec_error(r0)) continue;                       // empty or rejected: the dictionary passes
+        int r = r0;
+        if (dictLen > 0) {
+            const uint8_t *data = nullptr;
+            int compLen = 0, cap = 0;
+            r = read_block_header(a, f, data, compLen, cap);
+            if (r == 0 && (uint64_t)cap > a.ringStride) r = -1;
+            if (r == 0)
+                r = decode_block_par<false, true>(data, compLen, ring, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
+            r = uni(r);
+        }
+        if (r <= 0) {
+            // fails with its true dictionary (or there is none): the stream is broken here, the exact path reports it
+            if (lane_id() == 0) {
+                atomicOr(&a.runCtl[1], 1u);
+                __hip_atomic_store(&a.runDirty[p], RUNIN_CLEAN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (nobody waits for a call that has given up)
+            }
+            return;
+        }
+        uint8_t *dst = a.out + a.outOff[f];
+        const int old = uni(a.runRes[f - a.segFirst]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");       // the ring's bytes are this wave's own stores
+        const bool diff = wave_copy_changed(dst, ring, r) || old != r;
+        if (lane_id() == 0) a.runRes[f - a.segFirst] = r;
+        if (!diff) changed = false;
+        dict = dst; dictLen = (uint32_t)r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    if (lane_id() == 0) {
+        const int nPieces = (a.segEnd - a.segFirst + a.runPiece - 1) / a.runPiece;
+        if (changed && p + 1 < nPieces && a.runInfo[4 * (p + 1)] != RUNIN_EXACT) {
+            // the piece behind was made with another dictionary.  Dirty in this round: it is waiting for this wave; marked
+            // already: nothing to add
+            uint32_t seen = __hip_atomic_load(&a.runDirty[p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (seen != round && seen != round + 1u) {
+                if (__hip_atomic_compare_exchange_strong(&a.runDirty[p + 1], &seen, round + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    atomicAdd(&a.runCtl[0], 1u);
+                    break;
+                }
+            }
+        }
+        __hip_atomic_store(&a.runDirty[p], RUNIN_CLEAN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_runin_publish(DecodeArgs a)
+{
+    const int f = a.segFirst + (int)(blockIdx.x * 256u + threadIdx.x);
+    if (f >= a.segEnd) return;
+    if (a.result[f] <= 0) a.result[f] = a.runRes[f - a.segFirst];
+}
+
+void launch_runin_decode(const DecodeArgs &a, hipStream_t s)
 {
     const int n = a.segEnd - a.segFirst;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_twin_fix, dim3((unsigned)((n + a.twinPiece - 1) / a.twinPiece)), dim3(64), 0, s, a);
+    const int nPieces = (n + a.runPiece - 1) / a.runPiece;
+    hipLaunchKernelGGL(k_runin_decode, dim3((unsigned)nPieces), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_runin_verify, dim3((unsigned)nPieces), dim3(256), 0, s, a);
+}
+void launch_runin_fix(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_runin_fix, dim3((unsigned)((n + a.runPiece - 1) / a.runPiece)), dim3(64), 0, s, a);
+}
+void launch_runin_publish(const DecodeArgs &a, hipStream_t s)
+{
+    const int n = a.segEnd - a.segFirst;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_runin_publish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_linked_runs(const DecodeArgs &a, hipStream_t s)

@@ -19,8 +19,9 @@ size_t ptr_ctl_last_open_offset() { return 0; }
 void launch_longest_stream(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_linked_runs(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_link_stat(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
-void launch_twin_decode(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
-void launch_twin_fix(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_runin_decode(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_runin_fix(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_runin_publish(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 size_t tol_region_bytes() { return 65536; }
 void launch_encode(const EncodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_encode_seg(const EncodeSegArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }

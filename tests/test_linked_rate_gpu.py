@@ -196,18 +196,16 @@ def test_single_linked_stream_host_api_rate(engine, slz4, oracle, linked):
     print(rec)
 
 
-def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeypatch):
-    """ONE reference-written linked stream long enough (12 288 blocks of 64 KiB and more) that the default path is the
-    twin decode (pieces of 16 blocks decoded with two stand-ins for the missing dictionary, kernels.hip): its output must
-    be the input, and the same bytes as the pointer pass's (MI355LZ4_LINKED_TWIN=0).  Rates go to linked_rate.json."""
+def test_long_linked_stream_default_is_runin_decode(engine, slz4, oracle, monkeypatch):
+    """ONE reference-written linked stream long enough (10 240 blocks of 64 KiB and more) that the default path is the
+    run-in decode (pieces of the stream, each decoded from 11 blocks in front of it, kernels.hip): its output must be the
+    input, and the same bytes as the pointer pass's (MI355LZ4_LINKED_RUNIN=0).  Rates go to linked_rate.json."""
     import torch
     dev = torch.device("cuda:0")
     # Two copies of one stream of 6272 blocks laid end to end: still ONE valid linked stream, because the reference wrote the
-    # copy's first block without a dictionary.  That block (index 6272) decodes in the first pass; 6272 = 14 * 448 puts it
-    # at the END of piece 447 (pieces of 14 start at the first dependent block, 1), so that piece 448 -- the first of its
-    # wave in k_twin_begin -- has its TRUE dictionary in the middle of a segment: the case a wave-uniform shortcut got wrong
-    # in development (the 63 pieces behind it were marked final by their wave's first lane; bench.py's check found it).
-    # The last piece is ragged.
+    # copy's first block without a dictionary.  That block (index 6272) decodes in the first pass, so the pieces whose run-in
+    # would cross it start behind it with their TRUE dictionary in the middle of a segment (the twin decode of this round's
+    # first half got a case like it wrong in development: bench.py's check found it).  The last piece is ragged.
     bl, nb1, base = 65536, 6272, 1024
     d1 = oracle.gen("text", base, bl, first_block=555).tobytes()
     d1 = (d1 * ((nb1 + base - 1) // base))[: nb1 * bl]
@@ -216,7 +214,7 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
     for _ in range(extra):
         cut += 8 + int.from_bytes(fr1[cut:cut + 4], "little")
     data, fr, nb = d1 + d1 + d1[: extra * bl], fr1 + fr1 + fr1[:cut], 2 * nb1 + extra
-    assert nb - 1 >= 12288 and nb1 % 14 == 0 and (nb1 // 14) % 64 == 0
+    assert nb - 1 >= 10240
     offs = np.zeros(nb + 1, dtype=np.int64)
     pos = 0
     for i in range(nb):
@@ -230,11 +228,11 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
     res = torch.zeros(nb, dtype=torch.int32, device=dev)
     e0, e1 = slz4.Event(), slz4.Event()
     rates = {}
-    for label, env in (("twin (default)", None), ("pointer pass", "0")):
+    for label, env in (("run-in (default)", None), ("pointer pass", "0")):
         if env is None:
-            monkeypatch.delenv("MI355LZ4_LINKED_TWIN", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN", raising=False)
         else:
-            monkeypatch.setenv("MI355LZ4_LINKED_TWIN", env)
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN", env)
         out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
         best = 1e9
         for _ in range(2):
@@ -250,9 +248,9 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
-    assert rates["twin (default)"] > rates["pointer pass"]
-    # The same stream with payload bytes of three blocks corrupted: whatever the twin decode does with it (a block that fails
-    # with its true dictionary sends the rest of the span to the pointer pass), results and bytes must be those of the
+    assert rates["run-in (default)"] > rates["pointer pass"]
+    # The same stream with payload bytes of three blocks corrupted: whatever the run-in decode does with it (a block that fails
+    # with its dictionary sends the span to the pointer pass), results and bytes must be those of the
     # pointer pass alone -- which tests/test_parity_gpu.py holds against the oracle's codes on short streams.
     bad = buf.clone()
     for blk in (5000, 5001, nb - 3):
@@ -260,17 +258,17 @@ def test_long_linked_stream_default_is_twin_decode(engine, slz4, oracle, monkeyp
         n = int(offs[blk + 1]) - p0
         bad[p0 + n // 2:p0 + n // 2 + 48] = 0xff           # (tokens of 0xff: length fields that run past the block)
     outs = {}
-    for label, env in (("twin", None), ("pointer", "0")):
+    for label, env in (("runin", None), ("pointer", "0")):
         if env is None:
-            monkeypatch.delenv("MI355LZ4_LINKED_TWIN", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN", raising=False)
         else:
-            monkeypatch.setenv("MI355LZ4_LINKED_TWIN", env)
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN", env)
         out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
         r = torch.zeros(nb, dtype=torch.int32, device=dev)
         engine.decompress_batch_device(bad, len(fr), off, nb, out, ooff, r, linked=True)
         engine.synchronize()
         outs[label] = (r.cpu().numpy().copy(), out)
-    r_t, o_t = outs["twin"]
+    r_t, o_t = outs["runin"]
     r_p, o_p = outs["pointer"]
     assert (r_t == r_p).all(), np.nonzero(r_t != r_p)[0][:8]
     assert (r_p <= 0).any()                                  # (the corruption was felt)

@@ -1,4 +1,4 @@
-"""Soak test of the linked-stream decode (twin decode with tiny pieces, pointer pass, their fallbacks) against the oracle:
+"""Soak test of the linked-stream decode (run-in decode with tiny pieces and run-ins, pointer pass, their fallbacks) against the oracle:
 many random streams with random corruptions, ragged block sizes, random segment and piece sizes; every block's result
 (size or the reference's negative code) and every decoded byte must be the oracle's linked decode's.  200 trials by
 default (a second); LINKED_SOAK=<trials> LINKED_SOAK_SEED=<seed> for a real soak after a change to the linked paths
@@ -41,14 +41,18 @@ def test_linked_soak(engine, oracle, monkeypatch):
         monkeypatch.setenv("MI355LZ4_LINKED_PTR_BLOCKS", str(rng.choice([1, 2, 3, 7, 4096])))
         monkeypatch.setenv("MI355LZ4_LINKED_POOL_BLOCKS", str(rng.choice([2, 5, 16384, 16384])))
         if rng.random() < 0.4:
-            # the twin decode in front of all that (pieces that chain and run out of rounds; corrupted blocks send the rest
-            # of the span to the passes above): the reference's codes and bytes all the same
-            monkeypatch.setenv("MI355LZ4_LINKED_TWIN", "1")
-            monkeypatch.setenv("MI355LZ4_LINKED_TWIN_PIECE", str(rng.choice([1, 2, 3, 5])))
+            # the run-in decode in front of all that (pieces that are redone, chain and run out of rounds; corrupted blocks
+            # send the span to the passes above): the reference's codes and bytes all the same
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN", "1")
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN_PIECE", str(rng.choice([1, 2, 3, 5])))
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN_BLOCKS", str(rng.choice([1, 1, 2, 3, 11])))
+            monkeypatch.setenv("MI355LZ4_LINKED_RUNIN_SPIN", str(rng.choice([0, 10000, 10000])))
             monkeypatch.setenv("MI355LZ4_LINKED_RUNS", "0")
         else:
-            monkeypatch.delenv("MI355LZ4_LINKED_TWIN", raising=False)
-            monkeypatch.delenv("MI355LZ4_LINKED_TWIN_PIECE", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN_PIECE", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN_BLOCKS", raising=False)
+            monkeypatch.delenv("MI355LZ4_LINKED_RUNIN_SPIN", raising=False)
             monkeypatch.delenv("MI355LZ4_LINKED_RUNS", raising=False)
         dict_bytes, eres, eouts = None, [], []
         for b in split_blocks(bytes(fr)):

@@ -657,12 +657,16 @@ LINKED_VARIANTS = {
     # no host wait: the second pass is enqueued over all blocks, gated on the device (mi355lz4_set_linked_async)
     "async": {"MI355LZ4_LINKED_ASYNC": "4194304"},
     "async_segments_of_3": {"MI355LZ4_LINKED_ASYNC": "4194304", "MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
-    # twin decode (round 5; by default only for spans of 12 288 blocks and more): pieces of 16, and short pieces that chain --
-    # with and without the wait inside a launch -- and run out of rounds, which hands the rest to the pointer pass
-    "twin": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_RUNS": "0"},
-    "twin_pieces_of_2": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": "2", "MI355LZ4_LINKED_RUNS": "0"},
-    "twin_pieces_of_3_no_wait": {"MI355LZ4_LINKED_TWIN": "1", "MI355LZ4_LINKED_TWIN_PIECE": "3", "MI355LZ4_LINKED_TWIN_SPIN": "0",
-                                 "MI355LZ4_LINKED_RUNS": "0"},
+    # run-in decode (round 5; by default only for spans of 640 MiB and more): the default run-in (every piece starts at the
+    # stream's first block in these short streams), and run-ins too short to arrive at the true dictionary -- pieces redone,
+    # chained, with and without the wait inside a launch, calls given up for the pointer pass
+    "runin": {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNS": "0"},
+    "runin_1_pieces_of_1": {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNIN_BLOCKS": "1", "MI355LZ4_LINKED_RUNIN_PIECE": "1",
+                            "MI355LZ4_LINKED_RUNS": "0"},
+    "runin_2_pieces_of_2_no_wait": {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNIN_BLOCKS": "2", "MI355LZ4_LINKED_RUNIN_PIECE": "2",
+                                    "MI355LZ4_LINKED_RUNIN_SPIN": "0", "MI355LZ4_LINKED_RUNS": "0"},
+    "runin_1_pieces_of_3": {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNIN_BLOCKS": "1", "MI355LZ4_LINKED_RUNIN_PIECE": "3",
+                            "MI355LZ4_LINKED_RUNS": "0"},
 }
 
 
@@ -863,6 +867,9 @@ def test_single_linked_stream_deep_chains(engine, oracle, linked_variant):
         "zeros": bytes(40 * bl),
         "period 3": (b"abc" * (14 * bl // 3 + 1))[: 14 * bl],
         "period 70001": (oracle.gen("text", 2, bl, first_block=9).tobytes()[:70001] * 12)[: 11 * bl],
+        # every block is made of the block before it, noise otherwise: a run-in never arrives at the true dictionary, every
+        # piece would have to be redone behind the one in front (the run-in decode gives such a call up: k_runin_fix)
+        "period 60000 of noise": (random.Random(5).randbytes(60000) * 45)[: 40 * bl],
         "runs in text": b"".join(oracle.gen("text", 1, bl, first_block=i).tobytes()[:3000] + bytes([65 + i]) * 20000 for i in range(30)),
     }
     for name, d in cases.items():
