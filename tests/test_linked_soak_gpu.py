@@ -31,6 +31,11 @@ def test_linked_soak(engine, oracle, monkeypatch):
             d = d[:bl] * nblk
         elif shape < 0.3:
             d = bytes(len(d))
+        elif shape < 0.36:
+            # noise with a period just below the reach of an offset: every block is made of the block before it, a missing
+            # dictionary is never forgotten (the run-in decode's pieces are all to be redone, in a chain)
+            pat = random.Random(rng.getrandbits(32)).randbytes(rng.randint(40000, 65535))
+            d = (pat * (len(d) // len(pat) + 1))[: len(d)]
         fr = bytearray(oracle.frame_compress(d, bl, rng.choice([1, 1, 3, 50]), 8, True))
         blocks = split_blocks(bytes(fr))
         for _ in range(rng.choice([0, 0, 1, 1, 2, 5])):
