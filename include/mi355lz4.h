@@ -170,7 +170,7 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * decode on their own (everything this engine's compressor emits) are final
  * after the parallel kernel; blocks that reach into their predecessor are
  * resolved by a second, data-parallel pass: short runs of them by a wave per
- * run, spans of 640 MiB and more by the run-in decode (pieces of the span,
+ * run, spans of 576 MiB and more by the run-in decode (pieces of the span,
  * each decoded from a few blocks in front of it and checked against what the
  * piece in front wrote, DESIGN.md 0b: scratch two blocks per piece, at most
  * 4096 pieces),

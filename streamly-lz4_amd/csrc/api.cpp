@@ -618,7 +618,7 @@ static int linked_finish(mi355lz4_ctx *c)
 #define RUNIN_DEFAULT_64K 11
 #endif
 #ifndef RUNIN_MIN_SPAN
-#define RUNIN_MIN_SPAN 10240
+#define RUNIN_MIN_SPAN 9216
 #endif
 #define RUNIN_ROUNDS 8          // launches of pieces to be redone before the call is left to the pointer pass
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,

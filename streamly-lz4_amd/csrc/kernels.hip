@@ -644,7 +644,7 @@ __global__ PAR_OCC void k_decode_fixup_linked(DecodeArgs a)
             if (lane_id() == 0) a.result[blk] = r;
         }
         if (r > 0) { dict = dst; dictLen = (uint32_t)r; }          // :2331-2333, :2353-2355
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        wave_fence();       // (the next block reads this one through the pipeline that wrote it: no write-back, see k_runin_decode)
     }
 }
 
@@ -697,7 +697,7 @@ __global__ PAR_OCC void k_decode_fixup_runs(DecodeArgs a)
                 r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed,
                                                   a.framed + a.framedLen, lds, nullptr);
             r = uni(r);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");     // the block's bytes are out before its result says so
+            wave_fence();                                           // (one wave per run, nobody else looks before the launch ends)
             if (lane_id() == 0) a.result[f] = r;
         }
         if (r > 0) { dict = dst; dictLen = (uint32_t)r; }
@@ -805,7 +805,9 @@ __global__ RUNIN_OCC void k_runin_decode(DecodeArgs a)
             if (r == 0)
                 r = decode_block_par<false, true>(data, compLen, dst, cap, dict, dictLen, a.framed, a.framed + a.framedLen, lds, nullptr);
             r = uni(r);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // the next block reads this one through the vector cache
+            // (the next block reads this one through the same vector memory pipeline that wrote it, in order: nothing to wait
+            // for or to write back -- an agent-scope fence here is an L2 write-back per block and wave, measured below)
+            wave_fence();
         }
         if (own && lane_id() == 0) {
             a.runRes[f - a.segFirst] = r;
@@ -937,7 +939,7 @@ __global__ RUNIN_OCC void k_runin_fix(DecodeArgs a)
         }
         uint8_t *dst = a.out + a.outOff[f];
         const int old = uni(a.runRes[f - a.segFirst]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");       // the ring's bytes are this wave's own stores
+        wave_fence();                                            // (the ring's bytes are this wave's own stores)
         const bool diff = wave_copy_changed(dst, ring, r) || old != r;
         if (lane_id() == 0) a.runRes[f - a.segFirst] = r;
         if (!diff) changed = false;

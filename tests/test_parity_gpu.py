@@ -657,7 +657,7 @@ LINKED_VARIANTS = {
     # no host wait: the second pass is enqueued over all blocks, gated on the device (mi355lz4_set_linked_async)
     "async": {"MI355LZ4_LINKED_ASYNC": "4194304"},
     "async_segments_of_3": {"MI355LZ4_LINKED_ASYNC": "4194304", "MI355LZ4_LINKED_PTR": "1", "MI355LZ4_LINKED_POOL_BLOCKS": "3"},
-    # run-in decode (round 5; by default only for spans of 640 MiB and more): the default run-in (every piece starts at the
+    # run-in decode (round 5; by default only for spans of 576 MiB and more): the default run-in (every piece starts at the
     # stream's first block in these short streams), and run-ins too short to arrive at the true dictionary -- pieces redone,
     # chained, with and without the wait inside a launch, calls given up for the pointer pass
     "runin": {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNS": "0"},
