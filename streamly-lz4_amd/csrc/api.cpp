@@ -170,6 +170,8 @@ struct mi355lz4_ctx {
     int nSeg = 0;
     unsigned long long segTick = 0;
     int linkedAsyncCap = 0;                // > 0: linked device decodes do not wait on the host (mi355lz4_set_linked_async)
+    int runinSkip = 0;                     // linked decodes that go straight to the pointer pass: set when the run-in decode gave a call up because its
+                                           // data never forgets a dictionary (the calls that follow are, as a rule, more of the same stream)
     int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
@@ -621,6 +623,7 @@ static int linked_finish(mi355lz4_ctx *c)
 #define RUNIN_MIN_SPAN 9216
 #endif
 #define RUNIN_ROUNDS 8          // launches of pieces to be redone before the call is left to the pointer pass
+#define RUNIN_BACKOFF 16       // linked calls that skip the run-in decode after it gave one up for what the data is like
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
@@ -730,8 +733,9 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         const int span0 = last - first + 1;
         const uint64_t per64 = ((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u;
         const uint64_t stride = per64 * 65536u;
-        const bool useRunIn = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
-                              (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= RUNIN_MIN_SPAN));
+        bool useRunIn = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
+                        (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= RUNIN_MIN_SPAN));
+        if (useRunIn && !envRun && c->runinSkip > 0) { c->runinSkip--; useRunIn = false; }
         if (useRunIn) {
             // the taint of a missing dictionary is gone after 6 to 11 blocks of 64 KiB on text (scripts/runin_sim.py)
             // (64 KiB blocks: the 6th to 12th block is the first exact one; bigger blocks carry it further in bytes -- 256 KiB: 4
@@ -772,10 +776,13 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                         launch_runin_fix(a, c->stream);
                         HIP_TRY(hipMemcpyAsync(stat, a.runCtl, 8, hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(hipStreamSynchronize(c->stream));
-                        if (stat[1] != 0) break;                 // a block failed with the dictionary it got
+                        if (stat[1] != 0) break;                 // a block failed with the dictionary it got, or a chain of dirty pieces
                         segDone = stat[0] == 0;
                     }
                     done = segDone;
+                    // given up for what the DATA is like (chains of pieces to redo, rounds that do not end), not for a broken block:
+                    // the next RUNIN_BACKOFF linked calls of this engine do not try
+                    if (!segDone && !(stat[1] & 1u) && !envRun) c->runinSkip = RUNIN_BACKOFF;
                     if (segDone) launch_runin_publish(a, c->stream);
                 }
             }

@@ -276,3 +276,45 @@ def test_long_linked_stream_default_is_runin_decode(engine, slz4, oracle, monkey
     good = torch.from_numpy((r_p == bl)).to(dev)
     same = (o_t.view(nb, bl) == o_p.view(nb, bl)).all(dim=1)
     assert bool((same | ~good).all().item())
+
+
+def test_long_linked_stream_that_never_forgets(slz4, oracle):
+    """A long stream whose every block is made of the block before it (noise with a period just under 64 KiB): no run-in
+    arrives at the true dictionary, the run-in decode gives the call up for the pointer pass (chains of pieces to redo) and
+    the engine's next linked calls do not try again.  Bytes and results exact every time; an engine of its own, so that the
+    shared one keeps its defaults."""
+    import random
+    import torch
+    dev = torch.device("cuda:0")
+    eng = slz4.Engine(0)
+    bl, nb = 65536, 9472
+    pat = random.Random(11).randbytes(60000)
+    data = (pat * (nb * bl // len(pat) + 1))[: nb * bl]
+    fr = oracle.frame_compress(data, bl, 1, 8, True)
+    offs = np.zeros(nb + 1, dtype=np.int64)
+    pos = 0
+    for i in range(nb):
+        offs[i] = pos
+        pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+    offs[nb] = pos
+    buf = torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).to(dev)
+    off = torch.from_numpy(offs).to(dev)
+    ooff = torch.arange(nb + 1, dtype=torch.int64, device=dev) * bl
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+    e0, e1 = slz4.Event(), slz4.Event()
+    ms = []
+    for _ in range(3):
+        out = torch.zeros(nb * bl, dtype=torch.uint8, device=dev)
+        res = torch.zeros(nb, dtype=torch.int32, device=dev)
+        eng.record(e0)
+        eng.decompress_batch_device(buf, len(fr), off, nb, out, ooff, res, linked=True)
+        eng.record(e1)
+        eng.synchronize()
+        ms.append(round(eng.elapsed_ms(e0, e1), 3))
+        assert bool((res == bl).all().item()) and torch.equal(out, src)
+        del out
+    rec = {"streams": 1, "blocks": nb, "block_len": bl, "data": "noise of period 60000, reference-linked, one stream",
+           "ms_first_call_gives_up": ms[0], "ms_next_calls": ms[1:]}
+    with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(rec)
