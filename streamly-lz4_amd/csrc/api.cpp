@@ -722,7 +722,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // Long runs of dependent blocks -- a stream written by the reference's compressor is ONE such run -- in pieces of
     // consecutive blocks, every piece decoded from a few blocks in front of it ("run-in": by the time the wave reaches
     // the piece the dictionary it carries is the true one; checked against what the piece in front wrote, redone where it
-    // is not: kernels.hip, "RUN-IN DECODE").  A call's serial chain is run-in + piece blocks (0.45 ms per 64 KiB), one
+    // is not: kernels.hip, "RUN-IN DECODE").  A call's serial chain is run-in + piece blocks (0.53 ms per 64 KiB of text), one
     // wave per piece, a ring of two blocks of scratch per piece.
     // MI355LZ4_LINKED_RUNIN: 0 = never, 1 = whenever it applies (the tests); MI355LZ4_LINKED_RUNIN_BLOCKS: blocks of
     // run-in; MI355LZ4_LINKED_RUNIN_PIECE: blocks per piece (default: as many as give every piece a wave slot of its own).

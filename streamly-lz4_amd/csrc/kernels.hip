@@ -738,7 +738,7 @@ __device__ __forceinline__ void dict_before(const DecodeArgs &a, int b0, const u
 // induction from the first piece (which has its true dictionary) the whole stream is exact.  A call's serial chain is
 // runIn + piece blocks.  (The first half of round 5 decoded every piece TWICE, with 0x00 and 0xFF as stand-ins, and
 // re-decoded what differed: exact as well, but a chain of piece + the longest re-decoded prefix with two waves per
-// piece -- 1 GiB of text 12.5 ms against 10.1, 4 GiB 30.6 against 16.6.)
+// piece -- 1 GiB of text 12.5 ms against 9.0, 4 GiB 30.6 against 14.9.)
 //   A piece whose run-in did not arrive at the true dictionary is DIRTY: k_runin_fix decodes its blocks again, in
 // order, from the final dictionary, each into the ring first; a block that comes out as it was ends the work (all that
 // follows depends on it alone), a piece that changes up to its last block marks the piece behind it dirty for the next
