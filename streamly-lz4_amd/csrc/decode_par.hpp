@@ -77,6 +77,12 @@ namespace lz4dev {
 #ifndef PAR_RANK
 #define PAR_RANK 1          // dependency masks from a bit vector of sequence starts (rank queries) instead of binary searches
 #endif
+#ifndef PAR_PRIO
+#define PAR_PRIO 0x33     // s_setprio per phase, two bits each: chain (bits 0-1), decode + literals + need (2-3), match rounds (4-5), flush +
+                          // window + speculation (6-7).  The phases that are chains of dependent LDS round trips go first among the 19
+                          // waves of a CU.  Measured (lzsynth / text, GB/s; 0: 996-1000 / 634-638): 0x03 998 / 633, 0x30 1009 / 639,
+                          // 0x33 1015 / 642-643, 0x3b 1010 / 642, 0x3f 1010 / 640, 0x27 1003 / 640, 0x36 1011 / 640
+#endif
 #ifndef PAR_WAVES
 #define PAR_WAVES 5         // occupancy target (waves per SIMD) the register allocator is held to (<= 102 VGPRs)
 #endif
@@ -345,6 +351,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 }
                 wave_fence();
                 lap(PS_T_SPEC);
+#if PAR_PRIO
+            if ((PAR_PRIO >> 0 & 3) != (PAR_PRIO >> 6 & 3)) __builtin_amdgcn_s_setprio(PAR_PRIO >> 0 & 3);
+#endif
 
                 // ---------------- 3. chain: sequence r -> lane r ----------------
                 c2 = (lane == 0) ? 2u * (uint32_t)wofs : absorb;   // 2 x token position
@@ -414,6 +423,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
             }
             }
             lap(PS_T_CHAIN);
+#if PAR_PRIO
+            if ((PAR_PRIO >> 2 & 3) != (PAR_PRIO >> 0 & 3)) __builtin_amdgcn_s_setprio(PAR_PRIO >> 2 & 3);
+#endif
 
             // ---------------- 4. decode own sequence, place it ----------------
             const bool has = c2 < absorb;
@@ -686,6 +698,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
 
             // ---------------- 7. near matches: dependency rounds ----------------
             lap(PS_T_NEED);
+#if PAR_PRIO
+            if ((PAR_PRIO >> 4 & 3) != (PAR_PRIO >> 2 & 3)) __builtin_amdgcn_s_setprio(PAR_PRIO >> 4 & 3);
+#endif
             need &= ~farm;                                              // far matches are already in place
             uint64_t done = ((nseq >= LZ4_WAVE) ? 0ull : (~0ull << nseq)) | farm;
             bool pending = act && nearSrc;                              // my match still has to be copied
@@ -814,6 +829,9 @@ __device__ int decode_block_par(const uint8_t *src, int srcLen, uint8_t *dst, in
                 }
             }
             lap(PS_T_MATCH);
+#if PAR_PRIO
+            if ((PAR_PRIO >> 6 & 3) != (PAR_PRIO >> 4 & 3)) __builtin_amdgcn_s_setprio(PAR_PRIO >> 6 & 3);
+#endif
 
             // ---------------- advance, 8. flush, slide ----------------
             op = opNext;

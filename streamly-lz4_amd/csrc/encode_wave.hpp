@@ -108,6 +108,19 @@ __device__ __forceinline__ int enc_scan_incl(int x)
     return x;
 }
 
+// s_setprio per phase of a pair of windows: probe + heads + requests (P), the wait for the groups' bytes + their lengths (M),
+// hits + the selection's scalar loop (S), finish + table (F).  Four waves share a SIMD's issue; the wave that is in its serial
+// selection, or has requests to get out, goes first.  Measured (lzsynth / text, GB/s; all 0: 196-197 / 183): P M S F =
+// 1 0 3 0: 201 / 186, 2 0 3 0: 201 / 186, 3 0 3 0: 201 / 185, 2 1 3 0: 202 / 186, 3 1 3 2: 201 / 186, 2 0 3 1: 202 / 187.
+#ifndef ENC_PRIO_P
+#define ENC_PRIO_P 2
+#define ENC_PRIO_M 0
+#define ENC_PRIO_S 3
+#define ENC_PRIO_F 1
+#endif
+#ifndef ENC_PRIO1
+#define ENC_PRIO1 1       // the same in the one-window-per-step form (blocks above 64 KiB, segments)
+#endif
 #ifndef ENC_END2_MINLEN
 #define ENC_END2_MINLEN 16        // forward length from which a match also registers (its end - 2), as the reference does behind every match
 #endif
@@ -832,16 +845,20 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const uint32_t pos = (uint32_t)(p0 + lane), pos8 = pos - 8u;
             if (pfPos != p0) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + pos);
             LW W;
+            if (ENC_PRIO1 && ENC_PRIO_P != ENC_PRIO_F) __builtin_amdgcn_s_setprio(ENC_PRIO_P);
             lw_probe(W, pos, pfV8, false);
             lw_heads(G, W, pos, pos8, 0u, 0ull, (uint32_t)pfV8, ~(uint32_t)pfV8);
             lw_loads(G, W, p0);
+            if (ENC_PRIO1 && ENC_PRIO_P != ENC_PRIO_M) __builtin_amdgcn_s_setprio(ENC_PRIO_M);
             ENC_LAP(0);
             commit_pending();                                  // (the requests are out: the last window's moves are looked at now)
             lw_measure(G, W, p0);
+            if (ENC_PRIO1 && ENC_PRIO_S != ENC_PRIO_M) __builtin_amdgcn_s_setprio(ENC_PRIO_S);
             lw_hits(G, W, p0, hc0, (uint32_t)lane + 8u, 0u);
             if (!W.hitm) {
                 // nothing here: every position is registered, the miss counter widens the stride (:957-967)
                 lw_insert(W, pos);
+                if (ENC_PRIO1 && ENC_PRIO_F != ENC_PRIO_S) __builtin_amdgcn_s_setprio(ENC_PRIO_F);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 missAcc += LZ4_WAVE;
                 pfPos = -1;
@@ -849,6 +866,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             }
             int pEnd = anchor;
             const uint64_t selm = lw_select(W, p0, pEnd);
+            if (ENC_PRIO1 && ENC_PRIO_F != ENC_PRIO_S) __builtin_amdgcn_s_setprio(ENC_PRIO_F);
             shapeWin += 1;
             if (shapeCounting) shapeLong += (int)__builtin_popcountll(selm & W.longm);
             ENC_LAP(1);
@@ -894,6 +912,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             { uint32_t x = (uint32_t)pfV8 ^ (uint32_t)pfV8b; asm volatile("" : "+v"(x)); }      // the bytes have arrived
             ENC_LAP(4);
 #endif
+            if (ENC_PRIO_P != ENC_PRIO_F) __builtin_amdgcn_s_setprio(ENC_PRIO_P);
             lw_probe(W0, pos0, pfV8, true);
             lw_probe(W1, pos1, pfV8b, true);
 #ifdef ENC_STATS
@@ -905,6 +924,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                      (uint32_t)pfV8b, (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pfV8, 63));
             lw_loads(G, W0, p0);
             lw_loads(G, W1, p1);
+            if (ENC_PRIO_P != ENC_PRIO_M) __builtin_amdgcn_s_setprio(ENC_PRIO_M);
             ENC_LAP(0);
             commit_pending();                                  // the pair before this one: its moves' results are looked at now
             int pEnd = anchor;
@@ -926,11 +946,13 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
 #endif
             lw_measure(G, W0, p0);
             lw_measure(G, W1, p1);
+            if (ENC_PRIO_S != ENC_PRIO_M) __builtin_amdgcn_s_setprio(ENC_PRIO_S);
             lw_hits(G, W0, p0, hc0, (uint32_t)lane + 8u, 0u);
             const uint64_t sel0 = lw_select(W0, p0, pEnd);
             const int pMid = pEnd;
             lw_hits(G, W1, p1, hc1, (uint32_t)lane + 72u, (uint32_t)__builtin_amdgcn_readlane((int)W0.hv, 63));
             const uint64_t sel1 = lw_select(W1, p1, pEnd);
+            if (ENC_PRIO_F != ENC_PRIO_S) __builtin_amdgcn_s_setprio(ENC_PRIO_F);
             shapeWin += 2;
             if (shapeCounting) shapeLong += (int)__builtin_popcountll(sel0 & W0.longm) + (int)__builtin_popcountll(sel1 & W1.longm);
             ENC_LAP(1);
