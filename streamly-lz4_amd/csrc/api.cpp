@@ -170,8 +170,10 @@ struct mi355lz4_ctx {
     int nSeg = 0;
     unsigned long long segTick = 0;
     int linkedAsyncCap = 0;                // > 0: linked device decodes do not wait on the host (mi355lz4_set_linked_async)
-    int runinSkip = 0;                     // linked decodes that go straight to the pointer pass: set when the run-in decode gave a call up because its
-                                           // data never forgets a dictionary (the calls that follow are, as a rule, more of the same stream)
+    // the run-in decode adapts to what the engine's streams are like (the calls that follow one are, as a rule, more of the same):
+    bool runinLong = false;                // a call was given up with the default run-in (chains of pieces to redo): the long one from here on
+    int runinLongOk = 0;                   // ... calls in a row that finished with it (after RUNIN_LONG_PROBE the default is tried again)
+    int runinSkip = 0;                     // ... and given up with the long one too: this many linked decodes go straight to the pointer pass
     int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
@@ -623,7 +625,9 @@ static int linked_finish(mi355lz4_ctx *c)
 #define RUNIN_MIN_SPAN 9216
 #endif
 #define RUNIN_ROUNDS 8          // launches of pieces to be redone before the call is left to the pointer pass
-#define RUNIN_BACKOFF 16       // linked calls that skip the run-in decode after it gave one up for what the data is like
+#define RUNIN_LONG_64K 17      // the long run-in (blocks of 64 KiB): taken after the default one gave a call up for what the data is like
+#define RUNIN_LONG_PROBE 32    // calls in a row finished with the long run-in before the default is tried again
+#define RUNIN_BACKOFF 16       // linked calls that skip the run-in decode after the long one gave a call up as well
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
@@ -733,15 +737,20 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         const int span0 = last - first + 1;
         const uint64_t per64 = ((uint64_t)stat[4] + 65535u) / 65536u > 0 ? ((uint64_t)stat[4] + 65535u) / 65536u : 1u;
         const uint64_t stride = per64 * 65536u;
+        // (the engine's own linked compressor probes every position and takes half of a text block from the block before it, the
+        // reference's a third: its streams forget a dictionary after 9 to 15 blocks instead of 5 to 12 and take the long run-in,
+        // which pays from twice the span)
+        const bool longRun = c->runinLong && !envRun;
         bool useRunIn = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
-                        (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= RUNIN_MIN_SPAN));
+                        (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= (longRun ? 2 * RUNIN_MIN_SPAN : RUNIN_MIN_SPAN)));
         if (useRunIn && !envRun && c->runinSkip > 0) { c->runinSkip--; useRunIn = false; }
         if (useRunIn) {
             // the taint of a missing dictionary is gone after 6 to 11 blocks of 64 KiB on text (scripts/runin_sim.py)
             // (64 KiB blocks: the 6th to 12th block is the first exact one; bigger blocks carry it further in bytes -- 256 KiB: 4
             // blocks, 1 MiB: 2, measured)
+            const uint64_t run64 = longRun ? RUNIN_LONG_64K : RUNIN_DEFAULT_64K;
             int runIn = (envBlocks && atoi(envBlocks) > 0) ? atoi(envBlocks)
-                        : (per64 == 1 ? RUNIN_DEFAULT_64K : (int)((RUNIN_DEFAULT_64K + per64) / per64) + 1);
+                        : (per64 == 1 ? (int)run64 : (int)((run64 + per64) / per64) + 1);
             if (runIn > 64) runIn = 64;
             // pieces: one wave slot each (256 CUs x 16 waves), and at most 2 GiB of rings
             uint64_t maxPieces = ((uint64_t)1 << 31) / (2u * stride);
@@ -782,13 +791,18 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                     done = segDone;
                     // given up for what the DATA is like (chains of pieces to redo, rounds that do not end), not for a broken block:
                     // the next RUNIN_BACKOFF linked calls of this engine do not try
-                    if (!segDone && !(stat[1] & 1u) && !envRun) c->runinSkip = RUNIN_BACKOFF;
+                    if (!segDone && !(stat[1] & 1u) && !envRun) {
+                        if (!longRun) c->runinLong = true;
+                        else c->runinSkip = RUNIN_BACKOFF;
+                        c->runinLongOk = 0;
+                    }
                     if (segDone) launch_runin_publish(a, c->stream);
                 }
             }
             (void)hipGetLastError();
             a.ring = nullptr; a.zeroPage = nullptr; a.runRes = nullptr; a.runCtl = nullptr; a.runInfo = nullptr; a.runDirty = nullptr;
             a.runPiece = 0; a.runIn = 0;
+            if (done && longRun && ++c->runinLongOk >= RUNIN_LONG_PROBE) { c->runinLong = false; c->runinLongOk = 0; }
             if (done) { link_scratch_release(c); return check_launch("decode launch"); }
             // Not finished this way (a broken block, rounds that run out, no scratch): the segments that did finish are final,
             // the one that did not has the first pass's results still; its blocks go through the passes below
