@@ -111,7 +111,8 @@ __device__ __forceinline__ int enc_scan_incl(int x)
 // s_setprio per phase of a pair of windows: probe + heads + requests (P), the wait for the groups' bytes + their lengths (M),
 // hits + the selection's scalar loop (S), finish + table (F).  Four waves share a SIMD's issue; the wave that is in its serial
 // selection, or has requests to get out, goes first.  Measured (lzsynth / text, GB/s; all 0: 196-197 / 183): P M S F =
-// 1 0 3 0: 201 / 186, 2 0 3 0: 201 / 186, 3 0 3 0: 201 / 185, 2 1 3 0: 202 / 186, 3 1 3 2: 201 / 186, 2 0 3 1: 202 / 187.
+// 1 0 3 0: 201 / 186, 2 0 3 0: 201 / 186, 3 0 3 0: 201 / 185, 2 1 3 0: 202 / 186, 3 1 3 2: 201 / 186, 2 0 3 1: 202 / 187,
+// 2 0 3 2: 200 / 183, 3 1 3 1: 200 / 185; the emission at 0 or 3 instead of F: 202 / 186.
 #ifndef ENC_PRIO_P
 #define ENC_PRIO_P 2
 #define ENC_PRIO_M 0
