@@ -741,13 +741,14 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         // reference's a third: its streams forget a dictionary after 9 to 15 blocks instead of 5 to 12 and take the long run-in,
         // which pays from twice the span)
         const bool longRun = c->runinLong && !envRun;
-        bool useRunIn = !streamFirst && !a.asyncGate && !splitOk && !deferEnd &&
+        // (a range begun with mi355lz4_decompress_linked_begin that has no seam to wait for -- the stream's first range --
+        // is finished here like a plain call: _end and _end_last then find nothing left to do)
+        bool useRunIn = !streamFirst && !a.asyncGate && (!(splitOk || deferEnd) || lookBack == 0) &&
                         (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= (longRun ? 2 * RUNIN_MIN_SPAN : RUNIN_MIN_SPAN)));
         if (useRunIn && !envRun && c->runinSkip > 0) { c->runinSkip--; useRunIn = false; }
         if (useRunIn) {
-            // the taint of a missing dictionary is gone after 6 to 11 blocks of 64 KiB on text (scripts/runin_sim.py)
-            // (64 KiB blocks: the 6th to 12th block is the first exact one; bigger blocks carry it further in bytes -- 256 KiB: 4
-            // blocks, 1 MiB: 2, measured)
+            // run-in length: on text the 5th to 12th block of 64 KiB is the first without a byte of the missing dictionary
+            // (scripts/runin_sim.py); bigger blocks carry it further in bytes -- 256 KiB: 4 blocks, 1 MiB: 2, measured
             const uint64_t run64 = longRun ? RUNIN_LONG_64K : RUNIN_DEFAULT_64K;
             int runIn = (envBlocks && atoi(envBlocks) > 0) ? atoi(envBlocks)
                         : (per64 == 1 ? (int)run64 : (int)((run64 + per64) / per64) + 1);
@@ -790,7 +791,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                     }
                     done = segDone;
                     // given up for what the DATA is like (chains of pieces to redo, rounds that do not end), not for a broken block:
-                    // the next RUNIN_BACKOFF linked calls of this engine do not try
+                    // the engine's next calls take the long run-in, or -- that was the long one -- RUNIN_BACKOFF of them do not try
                     if (!segDone && !(stat[1] & 1u) && !envRun) {
                         if (!longRun) c->runinLong = true;
                         else c->runinSkip = RUNIN_BACKOFF;

@@ -69,12 +69,18 @@ def _worker(rank, world, port, kind, n_blocks, cuts, q, early=True, env=None):
 @pytest.mark.parametrize("kind,n_blocks,cuts,early", [("text", 48, [0, 20, 48], True), ("shared", 40, [0, 1, 40], True),
                                                       ("text", 96, [0, 30, 61, 96], True), ("lzsynth", 16, [0, 8, 16], True),
                                                       ("text", 56, [0, 30, 56], False),
-                                                      ("text", 44, [0, 21, 44], "segments")])
+                                                      ("text", 44, [0, 21, 44], "segments"),
+                                                      ("text", 52, [0, 27, 52], "runin")])
 def test_one_linked_stream_over_ranks(kind, n_blocks, cuts, early):
     """early: a rank hands its last block on before the rest of its range is fetched (mi355lz4_decompress_linked_end_last);
     "segments": the pointer pass is given 8 blocks at a time, so a range is several segments, the last block is not
-    available ahead and the call must say so (the driver then finishes the range first)."""
+    available ahead and the call must say so (the driver then finishes the range first); "runin": the first range through
+    the run-in decode."""
     env = {"MI355LZ4_LINKED_PTR_BLOCKS": "8"} if early == "segments" else None
+    if early == "runin":
+        # the stream's first range has no seam to wait for: it is finished in _begin by the run-in decode (forced here: by
+        # default only ranges of 9 216 blocks and more), pieces of 3 with a run-in of 2 blocks; the other range as always
+        env = {"MI355LZ4_LINKED_RUNIN": "1", "MI355LZ4_LINKED_RUNIN_PIECE": "3", "MI355LZ4_LINKED_RUNIN_BLOCKS": "2", "MI355LZ4_LINKED_RUNS": "0"}
     early = bool(early)
     world = len(cuts) - 1
     ctx = mp.get_context("spawn")
