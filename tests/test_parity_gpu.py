@@ -677,6 +677,33 @@ def linked_variant(request, monkeypatch):
     return request.param
 
 
+def test_engine_written_linked_stream_all_linked_paths(engine, oracle, linked_variant):
+    """A linked stream written by the ENGINE's linked compressor (deeper into its predecessors than the reference's: half of
+    a text block's bytes derive from the block before it) through every linked decode path of LINKED_VARIANTS -- among them
+    the run-in decode with run-ins too short for it -- and through the oracle's linked decoder: the input every time.
+    Ragged and empty blocks included."""
+    engine.set_linked_compress(True)
+    try:
+        for kind, bl, n in (("text", 65536, 30), ("text", 16384, 23), ("lzsynth", 65536, 14)):
+            data = oracle.gen(kind, n, bl, first_block=41).tobytes()
+            blocks = [data[i * bl:(i + 1) * bl] for i in range(n)]
+            fr, flen = engine.compress_batch(blocks)
+            assert oracle.frame_decompress(fr, n * bl, 8, 0, True) == data
+            out, res, ulen, _ = _decode_streams(engine, [fr], "one")
+            assert res == ulen == [bl] * n and out == data, (kind, bl)
+        sizes = [65536, 1000, 65536, 0, 13, 12, 40000, 65536, 65536, 5, 65536, 30000]
+        data = oracle.gen("text", 9, 65536, first_block=6).tobytes()
+        blocks, pos = [], 0
+        for sz in sizes:
+            blocks.append(data[pos:pos + sz])
+            pos += sz
+        fr, flen = engine.compress_batch(blocks)
+        out, blen = engine.decompress_batch(fr, linked=True)
+        assert blen == sizes and out == data[:pos]
+    finally:
+        engine.set_linked_compress(False)
+
+
 @pytest.mark.parametrize("decoder", [1, 2])
 def test_linked_streams_many(engine, oracle, decoder, linked_variant):
     engine.set_decoder(decoder)
