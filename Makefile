@@ -11,7 +11,7 @@ CSRC  := $(PKG)/csrc
 LIB   := $(PKG)/lib/libmi355lz4.so
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 
-SRCS := $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/host_stream.cpp $(CSRC)/lz4_frame.cpp
+SRCS := $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/host_stream.cpp $(CSRC)/lz4_frame.cpp $(CSRC)/multi_device.cpp
 HDRS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.h include/*.h)
 
 all: lib oracle
@@ -36,7 +36,7 @@ oracle:
 
 # Host-side sanitizer builds (CPU only; GPU ASan is not available on this pool): api.cpp + host_stream.cpp
 # compiled by g++ against the HIP host API, kernel launchers stubbed, driven by tests/native/host_san_test.cpp.
-SAN_SRCS := $(CSRC)/api.cpp $(CSRC)/host_stream.cpp $(CSRC)/lz4_frame.cpp tests/native/san_stubs.cpp tests/native/host_san_test.cpp
+SAN_SRCS := $(CSRC)/api.cpp $(CSRC)/host_stream.cpp $(CSRC)/lz4_frame.cpp $(CSRC)/multi_device.cpp tests/native/san_stubs.cpp tests/native/host_san_test.cpp
 SAN_FLAGS := -std=c++17 -O1 -g -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wall -Wno-unused-function -Wno-unused-result
 SAN_LIBS := -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -lpthread
 

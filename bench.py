@@ -151,6 +151,94 @@ def incompressible_rates(S, eng, torch, dev):
             "verified": True, "note": "HIP events, best of 3, device-resident"}
 
 
+def small_call_rates(S, eng, torch, dev, src, BL, kind, accel, with_cpu):
+    """The reference's own benchmark protocol is a SMALL call: 10 MiB per file (benchmark/Main.hs:80-84) = 160 blocks of
+    64 KiB.  The first 10 MiB of the bench's stream through one call each way: device-resident (HIP events; the decoder the
+    engine picks for a call of this size -- one workgroup per block, csrc/decode_cu.hpp -- and, beside it, the
+    one-wavefront-per-block decoder the 4 GiB figure is measured with), host buffer to host buffer through the C ABI
+    (pageable memory, wall clock), and the reference codec on the SAME bytes on one host core and on all of them."""
+    import ctypes as C
+    import numpy as np
+    NB = min((10 << 20) // BL, src.numel() // BL)
+    U = NB * BL
+    stride = S.slot_stride(BL, 8)
+    slots = torch.empty(NB * stride, dtype=torch.uint8, device=dev)
+    flen = torch.empty(NB, dtype=torch.int32, device=dev)
+    doff = torch.empty(NB + 1, dtype=torch.int64, device=dev)
+    dense = torch.empty(NB * stride, dtype=torch.uint8, device=dev)
+    ooff = torch.arange(NB + 1, dtype=torch.int64, device=dev) * BL
+    out = torch.empty(U, dtype=torch.uint8, device=dev)
+    res = torch.empty(NB, dtype=torch.int32, device=dev)
+    ev = [S.Event() for _ in range(3)]
+    tc = 1e9
+    Cb = 0
+    for _ in range(5):
+        eng.record(ev[0])
+        eng.compress_batch_device(src, NB, BL, slots, stride, flen, accel=accel)
+        eng.compact_device(slots, stride, flen, NB, dense, NB * stride, doff)
+        eng.record(ev[1])
+        eng.synchronize()
+        Cb = int(doff[-1].item())
+        tc = min(tc, eng.elapsed_ms(ev[0], ev[1]))
+    td = {}
+    for name, variant in (("decompress_ms", 0), ("decompress_one_wavefront_per_block_ms", 2)):
+        eng.set_decoder(variant)
+        best = 1e9
+        for _ in range(8):
+            out.zero_()
+            eng.record(ev[1])
+            eng.decompress_batch_device(dense, Cb, doff, NB, out, ooff, res)
+            eng.record(ev[2])
+            eng.synchronize()
+            best = min(best, eng.elapsed_ms(ev[1], ev[2]))
+        if not (bool((res == BL).all().item()) and torch.equal(out, src[:U])):
+            sys.exit("bench.py: small-call round trip mismatch (decoder %d)" % variant)
+        td[name] = round(best, 4)
+    eng.set_decoder(0)
+    r = {"workload": "first %d blocks of %d KiB (%.1f MiB) of the same %s stream, one call each way" % (NB, BL >> 10, U / 2 ** 20, kind),
+         "ratio": round(U / Cb, 4),
+         "device_resident": dict({"compress_ms": round(tc, 4)}, **td),
+         "note": "reference protocol: benchmark/Main.hs:80-84 (10 MiB per file); best of 5 / 8 calls"}
+    # host buffer to host buffer through the C ABI (what the Haskell shim's one FFI call per batch costs)
+    L = S.lib
+    u8p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    cap = NB * (S.compress_bound(BL) + 8)
+    host_t = torch.empty(U, dtype=torch.uint8); framed_t = torch.empty(cap, dtype=torch.uint8); out_t = torch.empty(U, dtype=torch.uint8)
+    host_t.copy_(src[:U].cpu())
+    ptrs = (u8p * NB)(*[C.cast(host_t.data_ptr() + i * BL, u8p) for i in range(NB)])
+    lens = np.full(NB, BL, dtype=np.int32)
+    fl = np.zeros(NB, dtype=np.int32); st = np.zeros(NB, dtype=np.int32); bl = np.zeros(NB, dtype=np.int32)
+    olen, dlen, got = C.c_size_t(), C.c_size_t(), C.c_int()
+    hc = hd = 1e9
+    for _ in range(7):
+        t0 = time.perf_counter()
+        rc = L.mi355lz4_compress_batch(eng.ctx, ptrs, lens.ctypes.data_as(i32p), NB, accel, 8, C.cast(framed_t.data_ptr(), u8p), cap,
+                                       C.byref(olen), fl.ctypes.data_as(i32p), st.ctypes.data_as(i32p))
+        t1 = time.perf_counter()
+        rc2 = L.mi355lz4_decompress_batch(eng.ctx, C.cast(framed_t.data_ptr(), u8p), olen.value, 8, 0, 0, None, 0,
+                                          C.cast(out_t.data_ptr(), u8p), U, C.byref(dlen), bl.ctypes.data_as(i32p), NB, C.byref(got))
+        t2 = time.perf_counter()
+        if rc != 0 or rc2 != 0 or dlen.value != U:
+            r["host_to_host"] = {"error": (L.mi355lz4_last_error() or b"").decode()}
+            return r
+        hc, hd = min(hc, t1 - t0), min(hd, t2 - t1)
+    if not torch.equal(out_t, host_t):
+        sys.exit("bench.py: small-call host round trip mismatch")
+    r["host_to_host"] = {"compress_ms": round(hc * 1e3, 4), "decompress_ms": round(hd * 1e3, 4), "memory": "pageable"}
+    if with_cpu:
+        from oracle import oracle as orc
+        hostb = host_t.numpy()
+        blocks = [hostb[i * BL:(i + 1) * BL].tobytes() for i in range(NB)]
+        one = orc.cpu_baseline(blocks, accel=accel)
+        allc = orc.cpu_baseline_all_cores(blocks, accel=accel)
+        r["cpu_same_bytes"] = {"kind": one["kind"],
+                               "one_core": {"compress_ms": round(one["comp_s"] * 1e3, 4), "decompress_ms": round(one["decomp_s"] * 1e3, 4)},
+                               "all_cores": {"cores": allc["threads"], "compress_ms": round(allc["comp_s"] * 1e3, 4),
+                                             "decompress_ms": round(allc["decomp_s"] * 1e3, 4),
+                                             "note": "best-case CPU, not reference behaviour: one stream per thread"}}
+    return r
+
+
 def host_api_rates(S, eng, src, BL, kind):
     """PCIe-inclusive rate of the host-buffer C API (what the Haskell shim binds) on the first 512 MiB of the
     same stream: pageable caller memory (staged through pinned slots) and page-locked caller memory (DMA
@@ -307,7 +395,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="decompress", choices=sorted(WORKLOADS))
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default: workload's)")
-    ap.add_argument("--decoder", type=int, default=0, help="0 auto, 1 sequence-at-a-time, 2 lane-parallel")
+    ap.add_argument("--decoder", type=int, default=0, help="0 chosen per call, 1 sequence-at-a-time, 2 one wavefront per block, 4 one workgroup per block")
     ap.add_argument("--linked", action="store_true", help="decode with linked = 1 (reference stream semantics)")
     ap.add_argument("--linked-compress", action="store_true",
                     help="compress this rank's blocks as ONE linked stream (previous block = dictionary, like the "
@@ -620,6 +708,8 @@ def main():
         line["incompressible"] = incompressible_rates(S, eng, torch, dev)
     if world == 1 and not args.no_host_api and kind != "canterbury-large":
         line["host_api_pcie_inclusive"] = host_api_rates(S, eng, src, BL, kind)
+    if world == 1 and not args.no_extra and not args.linked_compress and kind != "canterbury-large":
+        line["small_call"] = small_call_rates(S, eng, torch, dev, src, BL, kind, accel, not args.no_cpu_baseline)
     gather_failed = False
     if gather is not None:
         # compute-only is `value` (N x one GPU by construction: no collective in the timed region).  The numbers that
@@ -638,11 +728,13 @@ def main():
             gather["compress_plus_gather_GBps"] = round(world * U / (cm + gather["ms"]) / 1e6, 2)
         if extra is not None and "ms" in gather:
             line["roundtrip_plus_gather_GBps"] = round(world * U / (extra["roundtrip_ms_per_step"] + gather["ms"]) / 1e6, 2)
-        gather["note"] = ("no RCCL rank had run this code before the first driver SCALE run: the gather is covered by gloo "
-                          "tests with 2 and 3 ranks and a gloo rehearsal on one GPU")
+        try:
+            gather["backend"] = dist.get_backend()              # "nccl" = RCCL on ROCm; "gloo" = a rehearsal without xGMI
+        except Exception:
+            pass
         line["gather"] = gather
         if gather.get("error") or gather.get("verified") is False:
-            line["verified"] = False            # surfaced at top level whatever went wrong with the gather
+            line["gather_verified"] = False     # (`value` is verified on its own: the gather is not in the timed region)
             # A gather that COMPLETED and delivered a stream that does not decode to the global input fails the run (exit
             # code 1 below): the ordered gather is then wrong.  A gather that could not run at all (an exception out of the
             # communication layer) is reported in the line and leaves the exit code alone: `value` does not depend on it.

@@ -31,6 +31,11 @@ module Streamly.Internal.LZ4.GPU
     , newEngine
     , freeEngine
     , setLinkedCompress
+    , MultiEngine
+    , newMultiEngine
+    , freeMultiEngine
+    , c_multiCompressBatch
+    , c_multiDecompressBatch
     , compressChunksGPU
     , decompressChunksRawGPU
     )
@@ -97,6 +102,37 @@ foreign import ccall safe "mi355lz4.h mi355lz4_decompress_streams"
     c_decompressStreams
         :: Ptr C_Engine -> Ptr Word8 -> CSize -> CInt -> CInt -> Ptr Int32 -> CInt
         -> Ptr Word8 -> CSize -> Ptr CSize -> Ptr Int32 -> CInt -> Ptr CInt -> IO CInt
+
+-- Several GPUs behind one handle (one process, host buffers: a host caller is bound by PCIe, one link per GPU).  The two
+-- batch calls take the arguments of c_compressBatch / c_decompressBatch (independent blocks) and give the same bytes; the
+-- batch is cut into one contiguous block range per device and the results lie in order in the caller's buffer
+-- (include/mi355lz4.h, "several GPUs behind one handle").
+data C_Multi
+newtype MultiEngine = MultiEngine (Ptr C_Multi)
+
+foreign import ccall safe "mi355lz4.h mi355lz4_create_multi"
+    c_createMulti :: Ptr (Ptr C_Multi) -> Ptr CInt -> CInt -> IO CInt
+foreign import ccall safe "mi355lz4.h mi355lz4_destroy_multi"
+    c_destroyMulti :: Ptr C_Multi -> IO ()
+foreign import ccall safe "mi355lz4.h mi355lz4_multi_compress_batch"
+    c_multiCompressBatch
+        :: Ptr C_Multi -> Ptr (Ptr Word8) -> Ptr Int32 -> CInt -> CInt -> CInt
+        -> Ptr Word8 -> CSize -> Ptr CSize -> Ptr Int32 -> Ptr Int32 -> IO CInt
+foreign import ccall safe "mi355lz4.h mi355lz4_multi_decompress_batch"
+    c_multiDecompressBatch
+        :: Ptr C_Multi -> Ptr Word8 -> CSize -> CInt -> CInt
+        -> Ptr Word8 -> CSize -> Ptr CSize -> Ptr Int32 -> CInt -> Ptr CInt -> IO CInt
+
+-- | One handle over the given HIP devices (e.g. @[0 .. 7]@ for a node).
+newMultiEngine :: [Int] -> IO MultiEngine
+newMultiEngine devs = alloca $ \pp -> allocaArray (length devs) $ \pd -> do
+    pokeArray pd (map fromIntegral devs)
+    rc <- c_createMulti pp pd (fromIntegral (length devs))
+    when (rc /= 0) $ error "mi355lz4_create_multi failed (no gfx950 device?)"
+    MultiEngine <$> peek pp
+
+freeMultiEngine :: MultiEngine -> IO ()
+freeMultiEngine (MultiEngine p) = c_destroyMulti p
 
 newEngine :: Int -> IO Engine
 newEngine dev = alloca $ \pp -> do

@@ -117,7 +117,11 @@ int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
  * slot used longest ago) until mi355lz4_destroy; automatic mode leaves the path alone once that scratch would pass
  * 1 GiB, a forced count does not. */
 int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
-/* Decoder variant: 0 = auto (default), 1 = sequence-at-a-time kernel, 2 = lane-parallel kernel.
+/* Decoder variant: 0 = chosen per call (default), 1 = sequence-at-a-time kernel, 2 = lane-parallel kernel (one wavefront
+ * per block: what fills the GPU when a call brings thousands of blocks), 4 = one workgroup per block (sixteen wavefronts
+ * share a block's output in LDS: a block's latency is 1.5-2 x shorter, a 4 MiB block's 2 x; independent blocks only, a
+ * linked call takes variant 2).  Variant 0 takes variant 4 for calls of up to 256 blocks (MI355LZ4_CU_BLOCKS in the
+ * environment overrides the count; 0 = never) and variant 2 otherwise.
  * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
 /* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block
@@ -181,7 +185,7 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * linked == 0 it only enqueues work.  Environment knobs of the second pass
  * (read per call; for tests and measurements): MI355LZ4_LINKED_RUNS,
  * MI355LZ4_LINKED_RUNIN (0 = never, 1 = always), MI355LZ4_LINKED_RUNIN_PIECE,
- * MI355LZ4_LINKED_RUNIN_BLOCKS,
+ * MI355LZ4_LINKED_RUNIN_BLOCKS, MI355LZ4_LINKED_RUNIN_SPIN (polls a piece waits for the piece in front of it inside a launch),
  * MI355LZ4_LINKED_PTR, MI355LZ4_LINKED_PTR_BLOCKS, MI355LZ4_LINKED_POOL_BLOCKS.
  * replaces: decompressChunk, Internal/LZ4.hs:291-336. */
 int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
@@ -249,6 +253,31 @@ int mi355lz4_decompress_batch(mi355lz4_ctx *ctx, const uint8_t *framedIn, size_t
 int mi355lz4_decompress_streams(mi355lz4_ctx *ctx, const uint8_t *framedIn, size_t inLen, int headerKind,
                                 int fixedUncomp, const int32_t *streamFirst, int nStreams, uint8_t *out,
                                 size_t cap, size_t *outLen, int32_t *blockLen, int maxBlocks, int *nBlocks);
+
+/* ---- several GPUs behind one handle, one process --------
+ * A host caller is bound by PCIe (one link per GPU), so for the Haskell process -- one process, host buffers -- more GPUs
+ * is more links.  A multi handle owns one engine per entry of devices[] (the same device may be named more than once).
+ * The two calls below take the arguments of mi355lz4_compress_batch / mi355lz4_decompress_batch (independent blocks:
+ * linked = 0, no dictionary) and give the same results, byte for byte: the batch is cut into one contiguous block range
+ * per device (equal shares of the uncompressed bytes), every range goes through its engine's host-buffer call on a host
+ * thread of its own, and the results lie in order in the caller's one buffer -- a host consumer needs no gather.
+ * (Between ranks the north star's block i -> GPU i mod n is used, with a kernel on the root that interleaves the ranks'
+ * outputs, gather.py; towards host memory that would make every device-to-host copy one copy per block.)
+ * A handle is not thread-safe (one call at a time), like an engine.  mi355lz4_multi_last_error is thread-local.
+ * replaces: compressChunk / decompressChunk, Internal/LZ4.hs:226-281, :291-336, one FFI call per batch. */
+typedef struct mi355lz4_multi mi355lz4_multi;
+int mi355lz4_create_multi(mi355lz4_multi **out, const int *devices, int n);
+void mi355lz4_destroy_multi(mi355lz4_multi *m);
+int mi355lz4_multi_device_count(const mi355lz4_multi *m);
+/* engine i of the handle (e.g. for mi355lz4_set_decoder); owned by the handle */
+mi355lz4_ctx *mi355lz4_multi_engine(mi355lz4_multi *m, int i);
+const char *mi355lz4_multi_last_error(void);
+int mi355lz4_multi_compress_batch(mi355lz4_multi *m, const uint8_t *const *src, const int32_t *srcLen, int nBlocks,
+                                  int accel, int headerKind, uint8_t *framedOut, size_t cap, size_t *outLen,
+                                  int32_t *blockFramedLen, int32_t *status);
+int mi355lz4_multi_decompress_batch(mi355lz4_multi *m, const uint8_t *framedIn, size_t inLen, int headerKind,
+                                    int fixedUncomp, uint8_t *out, size_t cap, size_t *outLen, int32_t *blockLen,
+                                    int maxBlocks, int *nBlocks);
 
 /* ---- one linked stream over several GPUs ----------
  * A linked stream does not shard by round-robin: block k's dictionary is the

@@ -1,4 +1,4 @@
-"""Development aid: randomized differential soak of the decoders (variants 1, 2, 3) against the input, over data shapes that
+"""Development aid: randomized differential soak of the decoders (variants 1, 2, 4 and, in the experiment build, 3) against the input, over data shapes that
 move the lane-parallel kernel between its forms: sequence sizes around the 6 / 8 nodes-per-lane switch, deep dependency
 chains (short offsets), self-overlapping matches, long literal runs, tiny and huge blocks, ragged last blocks.
     python scripts/soak_decode.py [seconds] [seed]"""
@@ -47,7 +47,7 @@ while time.time() - t0 < budget:
     accel = rng.choice([1, 1, 1, 4, 64])
     fr_ref = o.frame_compress(data, bl, accel, 8, False)                 # reference-written independent blocks
     comp_gpu = eng.compress_batch([data[i:i + bl] for i in range(0, len(data), bl)], accel=accel)[0]
-    for dv in ((1, 2, 3) if S.Engine.has_experiments() else (1, 2)):
+    for dv in ((1, 2, 3, 4) if S.Engine.has_experiments() else (1, 2, 4)):
         eng.set_decoder(dv)
         out, blen = eng.decompress_batch(fr_ref)
         assert out == data, ("ref stream", dv, bl, nb, lit_max, off_max, mlen_max, accel, cases)

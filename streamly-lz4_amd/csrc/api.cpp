@@ -179,6 +179,7 @@ struct mi355lz4_ctx {
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
     bool linkBusy = false;
     unsigned long long *stats = nullptr;   // diagnostics: device counters of the lane-parallel decoder (off by default)
+    uint32_t *cuDbg = nullptr;             // diagnostics: 16 words per block from the workgroup-per-block decoder (mi355lz4_debug_cu)
 };
 
 static int dev_reserve(DevBuf &b, size_t bytes)
@@ -387,12 +388,13 @@ extern "C" int mi355lz4_debug_has_experiments(void)
 
 extern "C" int mi355lz4_set_decoder(mi355lz4_ctx *c, int variant)
 {
+    // 0 = chosen per call, 1 = sequence at a time, 2 = lane-parallel (one wavefront per block), 4 = one workgroup per block
+    // (decode_cu.hpp); 3 = the parse as a pass of its own (token lists), experiment builds only (make lib-exp)
+    bool ok = c && (variant == 0 || variant == 1 || variant == 2 || variant == 4);
 #ifdef MI355LZ4_EXPERIMENTS
-    const int top = 3;       // 3 = the parse as a pass of its own (token lists), experiment builds only (make lib-exp)
-#else
-    const int top = 2;
+    ok = ok || (c && variant == 3);
 #endif
-    if (!c || variant < 0 || variant > top) return fail(MI355LZ4_E_ARG, "bad decoder variant");
+    if (!ok) return fail(MI355LZ4_E_ARG, "bad decoder variant");
     c->decoder = variant;
     return MI355LZ4_OK;
 }
@@ -416,6 +418,25 @@ extern "C" int mi355lz4_debug_stats(mi355lz4_ctx *c, int enable, unsigned long l
     if (enable && !c->stats) HIP_TRY(hipMalloc((void **)&c->stats, PAR_STATS_COUNT * 8));
     if (c->stats) HIP_TRY(hipMemset(c->stats, 0, PAR_STATS_COUNT * 8));
     if (!enable && c->stats) { hipFree(c->stats); c->stats = nullptr; }
+    return MI355LZ4_OK;
+}
+
+// Diagnostic hook (not part of the public header): the run-in decode's adaptive state {runinLong, runinLongOk, runinSkip}.
+// get (may be null) receives it; set (may be null) replaces it.  Lets a test drive default -> long -> skip -> probe.
+extern "C" int mi355lz4_debug_runin_state(mi355lz4_ctx *c, int *get, const int *set)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    if (get) { get[0] = c->runinLong ? 1 : 0; get[1] = c->runinLongOk; get[2] = c->runinSkip; }
+    if (set) { c->runinLong = set[0] != 0; c->runinLongOk = set[1]; c->runinSkip = set[2]; }
+    return MI355LZ4_OK;
+}
+
+// Diagnostic hook (not part of the public header): the workgroup-per-block decoder writes 16 words per block of the
+// next calls to devBuf (caller-owned device memory, 64 bytes per block; null switches it off): decode_cu.hpp, `dbg`.
+extern "C" int mi355lz4_debug_cu(mi355lz4_ctx *c, uint32_t *devBuf)
+{
+    if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
+    c->cuDbg = devBuf;
     return MI355LZ4_OK;
 }
 
@@ -617,6 +638,16 @@ static int linked_finish(mi355lz4_ctx *c)
     return check_launch("decode launch");
 }
 
+// Blocks per call up to which the workgroup-per-block decoder is taken (decoder variant 0; MI355LZ4_CU_BLOCKS overrides, 0 = never)
+static int cu_auto_blocks()
+{
+    static const int v = [] {
+        const char *e = getenv("MI355LZ4_CU_BLOCKS");
+        return e ? atoi(e) : 256;
+    }();
+    return v;
+}
+
 // run-in decode of long linked streams: blocks of 64 KiB of run-in, and the span (in 64 KiB) from which it is the default
 #ifndef RUNIN_DEFAULT_64K
 #define RUNIN_DEFAULT_64K 11
@@ -652,7 +683,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
-    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.cuDbg = c->cuDbg;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
@@ -675,6 +706,11 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         launch_decode_tok(a, c->stream);
     }
 #endif
+    else if (!linked && !c->stats && (c->decoder == 4 || (c->decoder == 0 && nBlocks <= cu_auto_blocks())))
+        // Calls that do not fill the GPU -- one workgroup per block instead of one wavefront (decode_cu.hpp).  A CU takes about
+        // 0.16 ms per 64 KiB of a block, a wavefront 0.2-0.3 ms, but 19 wavefronts share a CU: with more blocks than CUs the
+        // wavefronts win.  (Variant 4 forces it for any number of blocks: the tests.)
+        launch_decode_cu(a, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
     if (!linked) return check_launch("decode launch");
@@ -716,7 +752,10 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             const int runs = (int)stat[6] > 0 ? (int)stat[6] : 1;
             if ((r = dev_reserve(c->tolMeta, ((size_t)runs + 1) * sizeof(int32_t)))) { link_scratch_release(c); return r; }
             a.runList = (int32_t *)c->tolMeta.p; a.runCap = runs;
-            HIP_TRY(hipMemsetAsync(a.runList, 0, sizeof(int32_t), c->stream));
+            if (hipMemsetAsync(a.runList, 0, sizeof(int32_t), c->stream) != hipSuccess) {
+                link_scratch_release(c);
+                return fail(MI355LZ4_E_HIP, "decompress: the run list could not be cleared");
+            }
             a.segFirst = first; a.segEnd = last + 1;
             launch_linked_runs(a, c->stream);
             link_scratch_release(c);
@@ -740,11 +779,18 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         // (the engine's own linked compressor probes every position and takes half of a text block from the block before it, the
         // reference's a third: its streams forget a dictionary after 9 to 15 blocks instead of 5 to 12 and take the long run-in,
         // which pays from twice the span)
+        // (the state decays with EVERY linked call that gets here, whatever path it then takes: an engine whose later streams are
+        // shorter than the long run-in's threshold would otherwise never try the default again)
+        if (!envRun && c->runinLong && ++c->runinLongOk >= RUNIN_LONG_PROBE) { c->runinLong = false; c->runinLongOk = 0; }
         const bool longRun = c->runinLong && !envRun;
         // (a range begun with mi355lz4_decompress_linked_begin that has no seam to wait for -- the stream's first range --
         // is finished here like a plain call: _end and _end_last then find nothing left to do)
+        // (a handful of huge blocks has the bytes but not the pieces: at least 64 dependent blocks; and a piece's ring is two
+        // strides, so strides beyond 1 GiB -- one piece would pass the 2 GiB the rings may take -- stay with the pointer pass)
         bool useRunIn = !streamFirst && !a.asyncGate && (!(splitOk || deferEnd) || lookBack == 0) &&
-                        (envRun ? atoi(envRun) != 0 : (plain && (uint64_t)span0 * per64 >= (longRun ? 2 * RUNIN_MIN_SPAN : RUNIN_MIN_SPAN)));
+                        (envRun ? atoi(envRun) != 0
+                                : (plain && span0 >= 64 && 2u * stride <= ((uint64_t)1 << 31) &&
+                                   (uint64_t)span0 * per64 >= (longRun ? 2 * RUNIN_MIN_SPAN : RUNIN_MIN_SPAN)));
         if (useRunIn && !envRun && c->runinSkip > 0) { c->runinSkip--; useRunIn = false; }
         if (useRunIn) {
             // run-in length: on text the 5th to 12th block of 64 KiB is the first without a byte of the missing dictionary
@@ -773,22 +819,27 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                 a.runInfo = (int32_t *)(meta + 65536 + (size_t)segBlocks * 4);
                 a.runDirty = (uint32_t *)(meta + 65536 + (size_t)segBlocks * 4 + nPiecesMax * 16);
                 a.runCtl = (uint32_t *)(meta + 65536 + (size_t)segBlocks * 4 + nPiecesMax * 20);
-                HIP_TRY(hipMemsetAsync(meta, 0x00, 65536, c->stream));
+                // (a failure in here leaves the linked scratch to the next call like every other error path: RUNIN_TRY; and a kernel
+                // that did not launch must not read as "nothing left to do": runCtl was zeroed by the host)
+#define RUNIN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { link_scratch_release(c); return fail(MI355LZ4_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+                RUNIN_TRY(hipMemsetAsync(meta, 0x00, 65536, c->stream));
                 done = true;
                 for (int s0 = first; s0 <= last && done; s0 += segBlocks) {
                     a.segFirst = s0; a.segEnd = (s0 + segBlocks < last + 1) ? s0 + segBlocks : last + 1;
-                    HIP_TRY(hipMemsetAsync(a.runCtl, 0, 8, c->stream));
+                    RUNIN_TRY(hipMemsetAsync(a.runCtl, 0, 8, c->stream));
                     launch_runin_decode(a, c->stream);
-                    bool segDone = false;
-                    for (int round = 0; round < RUNIN_ROUNDS && !segDone; round++) {
+                    bool segDone = false, launched = hipGetLastError() == hipSuccess;
+                    for (int round = 0; round < RUNIN_ROUNDS && !segDone && launched; round++) {
                         a.runRound = round;
-                        if (round) HIP_TRY(hipMemsetAsync(a.runCtl, 0, 4, c->stream));
+                        if (round) RUNIN_TRY(hipMemsetAsync(a.runCtl, 0, 4, c->stream));
                         launch_runin_fix(a, c->stream);
-                        HIP_TRY(hipMemcpyAsync(stat, a.runCtl, 8, hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(hipStreamSynchronize(c->stream));
+                        if (hipGetLastError() != hipSuccess) { launched = false; break; }
+                        RUNIN_TRY(hipMemcpyAsync(stat, a.runCtl, 8, hipMemcpyDeviceToHost, c->stream));
+                        RUNIN_TRY(hipStreamSynchronize(c->stream));
                         if (stat[1] != 0) break;                 // a block failed with the dictionary it got, or a chain of dirty pieces
                         segDone = stat[0] == 0;
                     }
+                    if (!launched) { stat[1] = 1u; segDone = false; }   // (left to the passes below, like a broken block)
                     done = segDone;
                     // given up for what the DATA is like (chains of pieces to redo, rounds that do not end), not for a broken block:
                     // the engine's next calls take the long run-in, or -- that was the long one -- RUNIN_BACKOFF of them do not try
@@ -800,19 +851,19 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                     if (segDone) launch_runin_publish(a, c->stream);
                 }
             }
-            (void)hipGetLastError();
+            (void)hipGetLastError();                             // (only a failed reservation is left to swallow here)
             a.ring = nullptr; a.zeroPage = nullptr; a.runRes = nullptr; a.runCtl = nullptr; a.runInfo = nullptr; a.runDirty = nullptr;
             a.runPiece = 0; a.runIn = 0;
-            if (done && longRun && ++c->runinLongOk >= RUNIN_LONG_PROBE) { c->runinLong = false; c->runinLongOk = 0; }
             if (done) { link_scratch_release(c); return check_launch("decode launch"); }
             // Not finished this way (a broken block, rounds that run out, no scratch): the segments that did finish are final,
             // the one that did not has the first pass's results still; its blocks go through the passes below
             a.segFirst = 0; a.segEnd = nBlocks;
-            HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
-            HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
+            RUNIN_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
+            RUNIN_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
             launch_link_stat(a, c->stream);
-            HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            RUNIN_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
+            RUNIN_TRY(hipStreamSynchronize(c->stream));
+#undef RUNIN_TRY
             if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
             first = (int)stat[1]; last = (int)stat[2];
             if (first < 0 || last >= nBlocks || first > last) {
@@ -1729,6 +1780,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
+    a.cuDbg = nullptr;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     if (s->dictLen) {

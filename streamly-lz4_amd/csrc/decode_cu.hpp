@@ -1,0 +1,892 @@
+// decode_cu.hpp -- one WORKGROUP (16 wavefronts = one CU) per LZ4 block: the decoder of calls that do not fill the GPU.
+//
+// Same contract and same results as decode_par.hpp / decode_seq.hpp (reference LZ4_decompress_generic,
+// cbits/lz4.c:1737-2165, with or without an external dictionary, :2347-2355).  decode_par.hpp gives a block to ONE
+// wavefront, which is what fills the chip when a call brings tens of thousands of blocks; but a wave on its own issues one
+// instruction in four to eight cycles and decodes 0.2-0.3 GB/s, so a call of 160 blocks -- the reference's own benchmark
+// protocol, benchmark/Main.hs:80-84 -- took one block's latency on a GPU that was 97 % idle, and a 4 MiB block
+// (Config.hs:109-116) took 24 ms.  Here a block is decoded in SEGMENTS of at most 42 KiB of compressed bytes and 64 KiB of
+// output; a segment's output lives in LDS and sixteen waves work on it:
+//
+//   1. stage      the segment's compressed bytes into LDS.
+//   2. parse      EXACT and parallel.  succ(p) = where the next token is if a token starts at byte p
+//                 (cbits/lz4.c:1801-1854).  Every lane takes a 32-byte chunk and computes, for every byte p of it,
+//                 T[p] = the first position at or behind the chunk's end that the chain from p reaches (backwards, so
+//                 T[p] = T[succ(p)] inside the chunk).  A chain can only ENTER a 512-byte super-chunk at a position some
+//                 T[p] names (a bit vector; 7 to 9 positions per super-chunk).  Each of those hops T[] through its
+//                 super-chunk (<= 16 hops); where they LEAVE it are the candidates (one or two per super-chunk: chains
+//                 that ran for 512 bytes have met).  The candidates form a linked list of <= 384 nodes which one wave
+//                 ranks by pointer doubling; the nodes reachable from the segment's first token are the true entries.
+//                 They hop once more to give every chunk its entry, every chunk's lane walks its few sequences, a scan
+//                 gives each sequence its index and output position.  Nothing is guessed.
+//   3. literals   every sequence's literals go from the compressed bytes to the output in LDS, and so does what a match
+//                 takes from in front of the segment (earlier segments' output or the dictionary, final in global
+//                 memory): no dependences.
+//   4. matches    a match is ready when the sequences its source overlaps are complete.  Sequence starts are bits of a
+//                 bit vector over the output (rank query = sequence index of a byte, as in decode_par.hpp step 5), every
+//                 sequence has a done bit; eight waves walk the dependence graph (depth 80-300 for 2400-6000 sequences),
+//                 each polling the done bits its 64 current sequences wait for: no barrier.
+//   5. flush      LDS -> global memory with aligned 16-byte stores.
+//   6. next       the first sequence that is not plain ends the segment.  If it is the output or table limit that ended it,
+//                 the next segment starts there; a sequence the parse does not take (a length with more than two extension bytes, an offset
+//                 of 0, a match that straddles the dictionary's end) is decoded by wave 0 with the sequential decoder and the
+//                 next segment starts behind it; the block's last 512 bytes (every end-of-block rule and every error code of
+//                 the reference) are decoded by the sequential decoder.
+//
+// Only plain interior sequences are taken by steps 2-5, as in decode_par.hpp.  A block that reports an error -- and anything
+// that goes wrong inside the form -- is marked CU_REDO and decoded again from scratch by the lane-parallel decoder
+// (k_decode_par_redo, the launch behind this one), which is what yields the reference's exact negative codes.  (This kernel
+// calls nothing out of line that another kernel calls: decode_seq_run, the one function the lane-parallel kernel calls, takes
+// its register budget from ALL its callers, and a 1024-thread caller cost that kernel a wave per SIMD.)
+#pragma once
+
+#include "decode_par.hpp"
+
+namespace lz4dev {
+
+#define CU_THREADS 1024
+#define CU_WAVES 16
+#define CU_CHUNK 32            // bytes of compressed stream per lane of the parse
+#define CU_SUPER 512           // bytes per super-chunk (16 chunks)
+#define CU_CAND0 16            // first-round candidates per super-chunk (every position a chunk's T[] names)
+#define CU_CAND 4              // candidate entries kept per super-chunk
+#define CU_NODES 384           // list nodes: super-chunks x candidates (<= 84 x 4), the last one is the list's end
+#define CU_LEVELS 7            // pointer doubling: the list has at most one node per super-chunk, 2^7 > 84
+#define CU_CMAX 43008          // compressed bytes of a segment (3.125 x CMAX + tables fit the LDS during the parse)
+#define CU_OUTMAX 65536        // output bytes of a segment
+#define CU_NMAX 8192           // sequences of a segment
+#define CU_GENS (CU_NMAX / CU_THREADS)
+#define CU_STOP 0xffffu        // T[]: the chain from here meets a sequence that is not plain before it leaves the chunk
+#define CU_NONE 0xffffu
+#define CU_REDO ((int)0x80000001)   // result of a block the form leaves to the lane-parallel decoder
+#define CU_IDLE_LIMIT 2000000u   // polls without progress after which a wave gives the block up (never reached: see there)
+#define CU_TAILMAX 512u         // compressed bytes left to the sequential decoder at the block's end
+#define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
+#ifndef CU_MWAVES
+#define CU_MWAVES 8u            // waves that walk the dependence graph (measured, 160 blocks lzsynth / text, us in this phase: 4 waves 80 / 95,
+                               // 8: 80 / 80, 16: 86 / 77; two groups per wave: 150 / 145 -- a poll costs instructions, not round trips)
+#endif
+#ifndef CU_SLOTS
+#define CU_SLOTS 1              // 64-sequence groups a wave works on at a time
+#endif
+
+// LDS map (bytes).  [0, 70 KiB): the compressed segment during the parse, the output afterwards.  Behind the compressed
+// bytes: T[], two bytes per compressed byte, dead once every chunk has its entry.  [70, 136 KiB): sequence records, written
+// by the chunks' second walk.  [136, 160 KiB): the parse's small tables, then the rank records and the done bits.
+// A SIMD issues one wave-instruction in four cycles and an LDS round trip is ~100 ns, so the phases are written for few
+// instructions and few dependent round trips, and both big tables are laid out for the access a whole wave makes at once
+// -- lane L working on chunk L:
+//   * the compressed bytes are staged with 4 bytes of padding behind every 32 (chunk stride 9 dwords: lanes that read
+//     "their" byte k hit 32 different banks; unpadded, chunk stride 8 dwords, they hit 4);
+//   * T[] is transposed: the entry of byte p lies at (p % 32) * chunks + p / 32, so the lanes' k-th entries are neighbours.
+#define CU_OFF_REC 71680
+#define CU_OFF_TAB 139264
+#define CU_LDS_BYTES 163840
+// ... tables of the parse
+#define CU_TAB_ENTRY 0         // u16[1408]   entry of every chunk
+#define CU_TAB_CBITS 2816      // u32[1408]   first-round candidate bits, one word per chunk;  then u16[7][384] doubling levels
+#define CU_TAB_CBITS1 8448     // u32[1408]   second-round candidate bits
+#define CU_TAB_CPOS0 14080     // u16[1408]   first-round candidates, 16 per super-chunk
+#define CU_TAB_CF0 16896       // u16[1408]   ... where each leaves its super-chunk
+#define CU_TAB_CPOS 19712      // u16[384]    candidates
+#define CU_TAB_CF 20480        // u16[384]    ... where each leaves its super-chunk
+#define CU_TAB_MARK 21248      // u8[384]
+#define CU_TAB_MISC 21632      // u32[32]     see CM_*
+#define CU_TAB_SCAN 21760      // u32[64]     workgroup scans
+#define CU_TAB_J CU_TAB_CBITS
+// ... after the parse
+#define CU_TAB_RANK 0          // uint4[1025]
+#define CU_TAB_DONE 16400      // u32[256]
+enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_COUNT };
+
+// byte p of the staged segment lives at LDS offset cu_at(p)
+__device__ __forceinline__ uint32_t cu_at(uint32_t p) { return p + ((p >> 5) << 2); }
+// four bytes from byte p on (two aligned dwords + a funnel; the dwords may lie either side of a chunk's padding)
+__device__ __forceinline__ uint32_t cu_u32(const uint8_t *comp, uint32_t p)
+{
+    const uint32_t a = p & ~3u;
+    const uint32_t d0 = *(const uint32_t *)(comp + cu_at(a)), d1 = *(const uint32_t *)(comp + cu_at(a + 4u));
+    return __builtin_amdgcn_alignbyte(d1, d0, p & 3u);
+}
+
+struct CuSeq { uint32_t litStart, lit, off, ml, nxt; bool odd; };   // nxt == CU_STOP: not a plain interior sequence; odd: and not for want of staged bytes
+
+// The sequence whose token is byte p of the segment (comp = the staged bytes in LDS), p < inLim - 2.  Plain = the whole
+// sequence ends at or before inLim = staged bytes - 32 (at the block's end the reference's fast loop can then neither fail on
+// input nor change loops, cbits/lz4.c:1809-1831, :1854-1863), offset != 0, and neither length has more than TWO extension
+// bytes (cbits/lz4.c:1707-1729: literal runs below 525, matches below 529 -- straight-line code, no loop; what is longer is
+// a few big copies, which the sequential decoder makes with the whole wave).  Every byte read lies at or before inLim + 3.
+// cu_lit() is the literal part from the token and the two bytes behind it alone: the parse computes the successor of EVERY
+// byte of the segment from registers, with one LDS read (the match length's extension byte) where the token asks for it.
+__device__ __forceinline__ void cu_lit(uint32_t t, uint32_t b1, uint32_t b1b, uint32_t &lit, uint32_t &litBytes, bool &bad)
+{
+    const uint32_t l0 = t >> 4;
+    const bool l15 = l0 == 15u, e1 = l15 && b1 == 255u;
+    lit = l15 ? 15u + b1 + (e1 ? b1b : 0u) : l0;
+    litBytes = l15 ? (e1 ? 2u : 1u) : 0u;
+    bad = e1 && b1b == 255u;
+}
+__device__ __forceinline__ CuSeq cu_parse(const uint8_t *comp, uint32_t p, uint32_t inLim)
+{
+    CuSeq s;
+    const uint32_t tb = cu_u32(comp, p);
+    const uint32_t t = tb & 0xffu;
+    uint32_t litBytes;
+    bool bad;
+    cu_lit(t, (tb >> 8) & 0xffu, (tb >> 16) & 0xffu, s.lit, litBytes, bad);
+    s.litStart = p + 1u + litBytes;
+    const uint32_t offPos = s.litStart + s.lit;
+    const uint32_t ob = cu_u32(comp, min(offPos, inLim));
+    s.off = ob & 0xffffu;
+    const bool mlx = (t & 15u) == 15u;
+    const uint32_t b2 = (ob >> 16) & 0xffu, b3 = ob >> 24;
+    const bool e2 = mlx && b2 == 255u;
+    s.ml = (t & 15u) + LZ4_MINMATCH + (mlx ? b2 : 0u) + (e2 ? b3 : 0u);
+    const uint32_t nxt = offPos + 2u + (mlx ? 1u : 0u) + (e2 ? 1u : 0u);
+    s.odd = nxt <= inLim && (bad || (e2 && b3 == 255u) || s.off == 0u);
+    s.nxt = (nxt <= inLim && !s.odd) ? nxt : CU_STOP;
+    return s;
+}
+
+// exclusive prefix sum over the workgroup's threads (v in thread order); *total = the sum.  tmp: 16 words of LDS.
+__device__ __forceinline__ uint32_t cu_scan_excl(uint32_t v, uint32_t *tmp, uint32_t *total)
+{
+    const int lane = lane_id(), wave = uni((int)(threadIdx.x >> 6));
+    const uint32_t incl = (uint32_t)par_scan_incl((int)v);
+    if (lane == LZ4_WAVE - 1) tmp[wave] = incl;
+    __syncthreads();
+    uint32_t w = (lane < CU_WAVES) ? tmp[lane] : 0u;
+    const uint32_t wi = (uint32_t)par_scan_incl((int)w);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(wi - w), wave);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)wi, CU_WAVES - 1);
+    __syncthreads();
+    return base + incl - v;
+}
+
+// n bytes (n >= 1) from global memory to LDS by one lane, 16 at a time (the last piece re-anchored at the end)
+__device__ __forceinline__ void cu_lane_fetch(uint8_t *out, uint32_t dA, const LZ4_GLOBAL uint8_t *g, uint32_t n)
+{
+    if (n >= 16u) {
+        const uint32_t last = n - 16u;
+        for (uint32_t o = 0;; o += 16u) {
+            const uint32_t oo = min(o, last);
+            *(par_v4u *)&out[dA + oo] = *(const LZ4_GLOBAL par_v4u *)(g + oo);
+            if (o >= last) break;
+        }
+    } else {
+        for (uint32_t o = 0; o < n; o++) out[dA + o] = g[o];
+    }
+}
+
+// One match by the whole wave (uniform arguments): the ones that overlap their own output (offset < length: the output is
+// the `off` bytes in front of the destination, repeated), and whatever else the lanes' own copy does not take.
+__device__ __forceinline__ void cu_wave_copy(uint8_t *out, uint32_t d, uint32_t s, uint32_t off, uint32_t ml)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    if (off >= ml && ml >= 16u) {
+        const uint32_t lastc = ml - 16u;
+        for (uint32_t o = 16u * lane; o < ml; o += 16u * LZ4_WAVE) {
+            const uint32_t oo = min(o, lastc);
+            const par_v4 v = *(const par_v4u *)&out[s + oo];
+            *(par_v4u *)&out[d + oo] = v;
+        }
+    } else if (off >= LZ4_WAVE) {
+        // (a step of 64 bytes reads what earlier steps wrote: LDS operations of one wave stay in order)
+        for (uint32_t c = 0; c < ml; c += LZ4_WAVE) {
+            const uint32_t j = c + lane;
+            if (j < ml) out[d + j] = out[s + j];
+            wave_fence();
+        }
+    } else {
+        uint32_t idx = lane % off;
+        const uint32_t step = LZ4_WAVE % off;
+        for (uint32_t j = lane; j < ml; j += LZ4_WAVE) {
+            out[d + j] = out[s + idx];
+            idx += step;
+            idx -= (idx >= off) ? off : 0u;
+        }
+    }
+    wave_fence();
+}
+
+// Decode one block with the whole workgroup.  All arguments uniform; dict / dictLen as in decode_block_par (DICT: the previous
+// block's output, linked streams).  Returns the block's result -- or CU_REDO -- in every thread.
+// dbg (diagnostics, may be null): [0] why the block was left to the lane-parallel decoder (0 = it was not; 2 too many
+// candidates, 3 no stop, 4 a wait without end, 5 a sequential step failed), [1] sequences of the first segment, [2] shader clocks
+// of the whole block, [3] polls << 16 | polls with progress of wave 0 in the first segment, [4..15] the 100 MHz clock at the first
+// segment's phase boundaries, [14] = start of the first step behind it, [15] = end of the block.
+// (forced inline: out of line, `lds` is a generic pointer and every LDS access a flat one -- measured 3-4 x on the parse)
+template <bool DICT>
+__device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict, uint32_t dictLen,
+                               const uint8_t *bufLo, const uint8_t *bufHi, uint8_t *lds, uint32_t *dbg = nullptr)
+{
+    int dbgAt = 4;
+    auto stamp = [&]() {
+        if (dbg && threadIdx.x == 0 && dbgAt < 16) dbg[dbgAt] = (uint32_t)wall_clock64();
+        dbgAt++;
+    };
+    uint32_t why = 0;
+    const uint32_t cyc0 = (uint32_t)clock64();
+    stamp();
+    const uint32_t tid = threadIdx.x;
+    const int lane = lane_id(), wave = uni((int)(tid >> 6));
+    uint8_t *comp = lds;
+    uint8_t *tab = lds + CU_OFF_TAB;
+    uint32_t *misc = (uint32_t *)(tab + CU_TAB_MISC);
+    uint32_t *scanTmp = (uint32_t *)(tab + CU_TAB_SCAN);
+    if (!DICT) { dict = nullptr; dictLen = 0; }
+    const uint8_t *dictEnd = DICT ? dict + dictLen : dst;
+    const int dictLo = DICT ? -(int)min(dictLen, 65535u) : 0;
+    int result = 0;
+    bool redo = false, finished = false;
+    // the block's state between segments (uniform): next token, output produced, which of the reference's loops is running
+    int ipBase = 0, opBase = 0;
+    bool fast = cap >= 64;                                        // cbits/lz4.c:1791
+    // (small blocks, and with them the reference's special cases of empty input and output, :1781-1787: the lane-parallel path)
+    if (cap < 256 || srcLen < (int)CU_MINSEG) { redo = true; why = 1; }
+
+    // One step of the sequential decoder by wave 0: seqMode 1 = one sequence, 2 = to the block's end, from (ipBase, opBase).
+    // (Called from ONE place, at the top of the loop below, and the decoder's body is expanded once inside a loop of two
+    // passes: every further expansion of it costs the kernel 2000 instructions and its registers.)
+    int seqMode = 0;
+    auto sequential = [&]() {
+        __threadfence_block();
+        __syncthreads();
+        if (wave == 0) {
+            SeqState st;
+            st.ip = ipBase; st.op = opBase; st.fast = fast;
+            int r = SEQ_CONTINUE;
+            for (int pass = 0; pass < 2 && r == SEQ_CONTINUE; pass++) {
+                // (what decode_par.hpp does behind a single sequence: once the reference would be in its safe loop, or near
+                // either end, the rest is sequential too)
+                const bool all = seqMode == 2 || pass == 1;
+                if (pass == 1 && !(!st.fast || srcLen - st.ip < 64 || cap - st.op < 128)) break;
+                r = decode_seq_body<false>(st, all ? 0 : 1, src, srcLen, dst, cap, dict, dictLen, bufLo, bufHi, nullptr);
+            }
+            r = uni(r);
+            if (lane == 0) { misc[CM_RESULT] = (uint32_t)r; misc[CM_NEXT_IP] = (uint32_t)uni(st.ip); misc[CM_NEXT_OP] = (uint32_t)uni(st.op); }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int r = (int)misc[CM_RESULT];
+        if (r == SEQ_CONTINUE) { ipBase = (int)misc[CM_NEXT_IP]; opBase = (int)misc[CM_NEXT_OP]; }
+        else if (r < 0) { redo = true; why = 5; }                  // the exact code comes from the one exact path
+        else { result = r; finished = true; }
+        __syncthreads();
+    };
+
+    for (int seg = 0; !redo && !finished; seg++) {
+        uint32_t remIn = (uint32_t)(srcLen - ipBase), remCap = (uint32_t)(cap - opBase);
+        if (!fast || remIn <= CU_TAILMAX || remIn < CU_MINSEG || remCap < 256u) seqMode = 2;
+        if (seqMode) {
+            sequential();
+            seqMode = 0;
+            if (redo || finished) break;
+            remIn = (uint32_t)(srcLen - ipBase); remCap = (uint32_t)(cap - opBase);
+            if (remIn <= CU_TAILMAX || remIn < CU_MINSEG || remCap < 256u) { seqMode = 2; continue; }
+        }
+        const uint8_t *ssrc = src + ipBase;
+        uint8_t *sdst = dst + opBase;
+        const uint32_t C = min(remIn, (uint32_t)CU_CMAX);        // bytes staged
+        const uint32_t capSeg = min(remCap, (uint32_t)CU_OUTMAX);
+        const uint32_t inLim = C - 32u;                          // a plain sequence ends at or before this
+        const uint32_t plim = inLim - 2u;                        // ... so its token lies before this
+        const uint32_t nChunks = (inLim + CU_CHUNK) / CU_CHUNK;  // T[] covers [0, inLim]
+        const uint32_t nSuper = (nChunks + 15u) / 16u;
+        const uint32_t NCH = 16u * nSuper;                       // chunks the tables are laid out for
+        const uint32_t nNodes = nSuper * CU_CAND;
+        uint16_t *Tt = (uint16_t *)(lds + ((cu_at(C + 64u) + 64u + 15u) & ~15u));
+        auto T_at = [&](uint32_t p) -> uint16_t & { return Tt[(p & 31u) * NCH + (p >> 5)]; };
+        uint16_t *entry = (uint16_t *)(tab + CU_TAB_ENTRY);
+        uint32_t *cbits = (uint32_t *)(tab + CU_TAB_CBITS);
+        uint32_t *cbits1 = (uint32_t *)(tab + CU_TAB_CBITS1);
+        uint16_t *cpos0 = (uint16_t *)(tab + CU_TAB_CPOS0);
+        uint16_t *cf0 = (uint16_t *)(tab + CU_TAB_CF0);
+        uint16_t *cpos = (uint16_t *)(tab + CU_TAB_CPOS);
+        uint16_t *cf = (uint16_t *)(tab + CU_TAB_CF);
+        uint16_t *J = (uint16_t *)(tab + CU_TAB_J);
+        uint8_t *mark = tab + CU_TAB_MARK;
+        if (seg) dbgAt = 16;                                     // (the stamps are the first segment's)
+
+        // ---------------- 1. stage ----------------
+        for (uint32_t i = tid; i < (C + 64u + 15u) / 16u; i += CU_THREADS) {
+            const uint8_t *q = ssrc + 16u * i;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (16u * i < C) {
+                if (q >= bufLo && q + 16 <= bufHi) {
+                    const par_v4 x = *(const LZ4_GLOBAL par_v4u *)q;
+                    w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+                } else {
+                    for (int k = 0; k < 16; k++)
+                        if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)as_global(q)[k] << (8 * (k & 3));
+                }
+            }
+            uint32_t *d = (uint32_t *)(comp + cu_at(16u * i));   // (16 bytes never straddle a chunk's padding)
+            d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+        }
+        for (uint32_t c = tid; c < NCH; c += CU_THREADS) { entry[c] = (uint16_t)CU_NONE; cbits[c] = 0u; cbits1[c] = 0u; }
+        if (tid < CU_NODES) { mark[tid] = 0; }
+        if (tid < CM_COUNT) misc[tid] = (tid == CM_NPAR) ? 0xffffffffu : 0u;
+        __syncthreads();
+        stamp();                                                 // [5] staged
+        if (tid == 0) { cbits[0] = 1u; cbits1[0] = 1u; }          // the segment's first token
+
+        // ---------------- 2a. successors, then T[] per chunk (backwards) ----------------
+        // The chunk's own bytes come in nine reads at once and every successor is computed from registers (cu_succ; one more
+        // read for the match length's extension byte); the backward pass -- T[p] = T[succ(p)] while succ(p) is in the chunk --
+        // runs in groups of three positions, which cannot name each other (a sequence is at least three bytes), so that a
+        // group is one LDS round trip.
+        for (uint32_t c = tid; c < nChunks; c += CU_THREADS) {
+            const uint32_t base = c * CU_CHUNK, cend = base + CU_CHUNK;
+            uint32_t W[9];
+            {
+                const uint32_t *wp = (const uint32_t *)(comp + cu_at(base));
+#pragma unroll
+                for (int j = 0; j < 8; j++) W[j] = wp[j];
+                W[8] = *(const uint32_t *)(comp + cu_at(base + 32u));
+            }
+            uint32_t S[CU_CHUNK];
+#pragma unroll
+            for (int k = 0; k < CU_CHUNK; k++) {
+                const uint32_t p = base + (uint32_t)k;
+                const uint32_t t = (W[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                const uint32_t b1 = (W[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu;
+                const uint32_t b1b = (W[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu;
+                uint32_t lit, litBytes;
+                bool bad;
+                cu_lit(t, b1, b1b, lit, litBytes, bad);
+                uint32_t nxt = p + 3u + litBytes + lit;
+                if ((t & 15u) == 15u) {                             // the match length's extension byte(s)
+                    nxt++;
+                    const uint32_t b2 = comp[cu_at(min(nxt - 1u, inLim))];
+                    if (b2 == 255u) { bad = bad || comp[cu_at(min(nxt, inLim))] == 255u; nxt++; }
+                }
+                S[k] = (!bad && p < plim && nxt <= inLim) ? nxt : CU_STOP;
+            }
+            // backwards, three positions at a time (k = 31, 30, 29; 28, 27, 26; ...; 1, 0)
+#pragma unroll
+            for (int g = CU_CHUNK - 1; g >= 0; g -= 3) {
+                uint32_t r[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int k = g - j;
+                    r[j] = CU_STOP;
+                    if (k >= 0 && S[k < 0 ? 0 : k] < cend) r[j] = T_at(S[k < 0 ? 0 : k]);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int k = g - j;
+                    if (k >= 0) {
+                        const uint32_t p = base + (uint32_t)k;
+                        const uint32_t sv = (S[k] < cend) ? r[j] : S[k];
+                        Tt[(uint32_t)k * NCH + c] = (uint16_t)sv;
+                        if (sv != CU_STOP && (sv / CU_SUPER) != (p / CU_SUPER)) atomicOr(&cbits[sv >> 5], 1u << (sv & 31u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        stamp();                                                 // [6] T[]
+
+        // ---------------- 2b. candidates of every super-chunk, and where each leaves it ----------------
+        // the j-th candidate (set bit) of super-chunk k in a bit vector with one word per chunk; *total = how many it has
+        auto nth_cand = [&](const uint32_t *bitsOf, uint32_t k, uint32_t j, uint32_t *total) -> uint32_t {
+            uint32_t bits[16];
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+                const uint4 v = *(const uint4 *)&bitsOf[16u * k + 4u * (uint32_t)w4];
+                bits[4 * w4] = v.x; bits[4 * w4 + 1] = v.y; bits[4 * w4 + 2] = v.z; bits[4 * w4 + 3] = v.w;
+            }
+            uint32_t pos = CU_NONE, seen = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const uint32_t pc = (uint32_t)__builtin_popcount(bits[w]);
+                if (pos == CU_NONE && seen + pc > j) {
+                    uint32_t b = bits[w];
+                    for (uint32_t r = j - seen; r; r--) b &= b - 1u;
+                    pos = (16u * k + (uint32_t)w) * 32u + (uint32_t)__builtin_ctz(b);
+                }
+                seen += pc;
+            }
+            *total = seen;
+            return pos;
+        };
+        // First every position some T[p] names (up to CU_CAND0 per super-chunk: chains that started a few bytes in front of
+        // the boundary have not met the true chain yet, 7 to 9 of them differ) hops through its super-chunk; where THOSE
+        // leave it are the candidates proper: a chain that has run for 512 bytes has, as a rule, met the true one -- one or
+        // two per super-chunk -- and the true entry is always among them, because the true entry of the super-chunk the
+        // chain came from was a first-round candidate there.
+        for (uint32_t n = tid; n < nSuper * CU_CAND0; n += CU_THREADS) {
+            const uint32_t k = n / CU_CAND0, j = n % CU_CAND0;
+            uint32_t total;
+            const uint32_t pos = nth_cand(cbits, k, j, &total);
+            if (j == 0 && total > CU_CAND0) misc[CM_OVERFLOW] = 1u;
+            const uint32_t send = (k + 1u) * CU_SUPER;
+            uint32_t q = pos;
+            if (pos != CU_NONE) {
+                for (int hop = 0; hop < 16 && q != CU_STOP && q < send; hop++) q = T_at(q);    // (a hop leaves a chunk: 16 at most)
+                if (q != CU_STOP && q < send) q = CU_STOP;
+                if (q != CU_STOP) atomicOr(&cbits1[q >> 5], 1u << (q & 31u));
+            }
+            cpos0[n] = (uint16_t)pos;
+            cf0[n] = (uint16_t)q;
+        }
+        __syncthreads();
+        // the candidates proper, with the exit the first round found for them
+        for (uint32_t n = tid; n < CU_NODES; n += CU_THREADS) {
+            uint32_t pos = CU_NONE, q = CU_NONE;
+            if (n < nNodes) {
+                const uint32_t k = n / CU_CAND, j = n % CU_CAND;
+                uint32_t total;
+                pos = nth_cand(cbits1, k, j, &total);
+                if (j == 0 && total > CU_CAND) misc[CM_OVERFLOW] = 1u;
+                if (pos != CU_NONE) {
+                    q = CU_STOP;
+                    bool found = false;
+#pragma unroll
+                    for (int j0 = 0; j0 < CU_CAND0; j0++)
+                        if (cpos0[k * CU_CAND0 + j0] == pos) { q = cf0[k * CU_CAND0 + j0]; found = true; }
+                    if (!found) misc[CM_OVERFLOW] = 1u;           // (a second-round candidate is a first-round one, or the segment's first byte)
+                }
+            }
+            cpos[n] = (uint16_t)pos;
+            cf[n] = (uint16_t)q;
+        }
+        __syncthreads();
+        // the list: node -> the node its exit is a candidate of (CU_NODES - 1 = the end)
+        for (uint32_t n = tid; n < CU_NODES; n += CU_THREADS) {
+            uint32_t nx = CU_NODES - 1u;
+            const uint32_t f = cf[n];
+            if (n < nNodes && cpos[n] != CU_NONE && f != CU_STOP) {
+                const uint32_t k2 = f / CU_SUPER;
+                bool found = false;
+                for (uint32_t j2 = 0; j2 < CU_CAND; j2++)
+                    if (k2 < nSuper && cpos[k2 * CU_CAND + j2] == f) { nx = k2 * CU_CAND + j2; found = true; }
+                if (!found) misc[CM_OVERFLOW] = 1u;
+            }
+            J[n] = (uint16_t)nx;
+        }
+        __syncthreads();
+        stamp();                                                 // [7] candidates, list
+
+        // ---------------- 2c. one wave: the nodes reachable from node 0 ----------------
+        if (wave == 0) {
+            for (int l = 1; l < CU_LEVELS; l++) {
+                const uint16_t *Jp = J + (l - 1) * CU_NODES;
+                uint16_t *Jn = J + l * CU_NODES;
+                uint32_t v[CU_NODES / LZ4_WAVE];
+#pragma unroll
+                for (int i = 0; i < CU_NODES / LZ4_WAVE; i++) v[i] = Jp[Jp[lane + LZ4_WAVE * i]];
+#pragma unroll
+                for (int i = 0; i < CU_NODES / LZ4_WAVE; i++) Jn[lane + LZ4_WAVE * i] = (uint16_t)v[i];
+                wave_fence();
+            }
+            if (lane == 0) mark[0] = 1;
+            wave_fence();
+            for (int l = CU_LEVELS - 1; l >= 0; l--) {
+                const uint16_t *Jl = J + l * CU_NODES;
+                uint32_t m[CU_NODES / LZ4_WAVE], t[CU_NODES / LZ4_WAVE];
+#pragma unroll
+                for (int i = 0; i < CU_NODES / LZ4_WAVE; i++) { m[i] = mark[lane + LZ4_WAVE * i]; t[i] = Jl[lane + LZ4_WAVE * i]; }
+#pragma unroll
+                for (int i = 0; i < CU_NODES / LZ4_WAVE; i++) if (m[i]) mark[t[i]] = 1;
+                wave_fence();
+            }
+        }
+        __syncthreads();
+        stamp();                                                 // [8] list ranked
+
+        // ---------------- 2d. the true entries hop through their super-chunk: every chunk's entry ----------------
+        if (tid < nNodes && mark[tid] && cpos[tid] != CU_NONE) {
+            uint32_t q = cpos[tid];
+            const uint32_t send = (tid / CU_CAND + 1u) * CU_SUPER;
+            for (int hop = 0; hop < 16 && q != CU_STOP && q < send; hop++) { entry[q / CU_CHUNK] = (uint16_t)q; q = T_at(q); }
+        }
+        __syncthreads();
+        if (misc[CM_OVERFLOW] != 0u) { redo = true; why = 2; }
+        stamp();                                                 // [9] entries
+        if (redo) break;
+
+        uint2 *rec = (uint2 *)(lds + CU_OFF_REC);
+        uint8_t *out = lds;
+        const uint32_t A = (uint32_t)((uintptr_t)sdst & 15u);    // LDS index of the segment's output position x is A + x
+
+        // ---------------- 2e. every chunk walks its sequences: counts, scan, records ----------------
+        // (thread t owns chunks 2t and 2t + 1: the scan runs in chunk order; the two are walked side by side: a sequence is
+        // two dependent LDS reads, and this way the two chunks' reads are in flight together)
+        uint32_t n2[2] = {0u, 0u}, len2[2] = {0u, 0u};
+        const uint32_t c0 = 2u * tid, c1 = 2u * tid + 1u;
+        const uint32_t e0 = (c0 < nChunks) ? (uint32_t)entry[c0] : CU_NONE, e1 = (c1 < nChunks) ? (uint32_t)entry[c1] : CU_NONE;
+        const uint32_t cend0 = (c0 + 1u) * CU_CHUNK, cend1 = (c1 + 1u) * CU_CHUNK;
+        {
+            uint32_t q0 = e0, q1 = e1;
+            bool a0 = c0 < nChunks && q0 < cend0, a1 = c1 < nChunks && q1 < cend1;     // (CU_NONE is beyond every chunk there is)
+            while (a0 || a1) {
+                const CuSeq s0 = cu_parse(comp, a0 ? q0 : 0u, inLim), s1 = cu_parse(comp, a1 ? q1 : 0u, inLim);
+                // (a chunk that stops takes one index for the token it stops at: T[] does not know everything the walk checks, so
+                // chunks behind a stop may have entries of their own, and every stop must have an index no other chunk has --
+                // the smallest one is the segment's end)
+                if (a0) { if (s0.nxt == CU_STOP) { a0 = false; n2[0]++; } else { n2[0]++; len2[0] += s0.lit + s0.ml; q0 = s0.nxt; a0 = q0 < cend0; } }
+                if (a1) { if (s1.nxt == CU_STOP) { a1 = false; n2[1]++; } else { n2[1]++; len2[1] += s1.lit + s1.ml; q1 = s1.nxt; a1 = q1 < cend1; } }
+            }
+        }
+        uint32_t totN, totLen;
+        const uint32_t seqBase = cu_scan_excl(n2[0] + n2[1], scanTmp, &totN);
+        const uint32_t opScan = cu_scan_excl(len2[0] + len2[1], scanTmp + 32, &totLen);
+        uint32_t myStop = 0xffffffffu, myStopIp = 0, myStopOp = 0, myStopKind = 0;
+        {
+            uint32_t q0 = e0, q1 = e1;
+            uint32_t i0 = seqBase, op0 = opScan, i1 = seqBase + n2[0], op1 = opScan + len2[0];
+            bool a0 = c0 < nChunks && q0 < cend0, a1 = c1 < nChunks && q1 < cend1;
+            // plain on the output side too: the source lies in the block -- or entirely in the dictionary --, the reference's
+            // fast loop would not change loops (cbits/lz4.c:1818, :1858-1863), and the sequence has a slot
+            auto step = [&](const CuSeq &sq, uint32_t &q, uint32_t &i, uint32_t &op, bool &act, uint32_t cend) {
+                const uint32_t outEnd = op + sq.lit + sq.ml;
+                const int sposBlk = opBase + (int)(op + sq.lit) - (int)sq.off;       // the source, relative to the block's output
+                const bool srcOk = sposBlk >= 0 || (DICT && sposBlk >= dictLo && sposBlk + (int)sq.ml <= 0);
+                const bool ok = sq.nxt != CU_STOP && srcOk && outEnd + 64u < capSeg && i < CU_NMAX;
+                if (!ok) {
+                    if (i < myStop) {                               // (the earlier of my two chunks' stops)
+                        myStop = i; myStopIp = q; myStopOp = op;
+                        myStopKind = (sq.nxt == CU_STOP ? (sq.odd ? 1u : 0u) : (!srcOk ? 1u : 0u));   // 1: one for the sequential decoder
+                    }
+                    act = false;
+                    return;
+                }
+                rec[i] = make_uint2(op | (sq.litStart << 16), sq.lit | (sq.off << 16));
+                i++; op = outEnd; q = sq.nxt;
+                act = q < cend;
+            };
+            while (a0 || a1) {
+                const CuSeq s0 = cu_parse(comp, a0 ? q0 : 0u, inLim), s1 = cu_parse(comp, a1 ? q1 : 0u, inLim);
+                if (a0) step(s0, q0, i0, op0, a0, cend0);
+                if (a1) step(s1, q1, i1, op1, a1, cend1);
+            }
+        }
+        if (myStop != 0xffffffffu) atomicMin(&misc[CM_NPAR], myStop);
+        __syncthreads();
+        const uint32_t nPar = misc[CM_NPAR];
+        if (myStop == nPar && nPar != 0xffffffffu) {
+            misc[CM_TAIL_IP] = myStopIp; misc[CM_TAIL_OP] = myStopOp; misc[CM_TAIL_KIND] = myStopKind;
+            rec[nPar] = make_uint2(myStopOp, 0u);                 // (the last match's length is the next record's start - ...)
+        }
+        __syncthreads();                                          // the compressed bytes and the parse's tables are dead from here on
+        if (nPar == 0xffffffffu) { redo = true; why = 3; }        // (cannot happen: a segment's last sequence is never plain)
+        stamp();                                                  // [10] records
+        if (dbg && tid == 0 && seg == 0) dbg[1] = nPar;
+        if (redo) break;
+        const uint32_t tailIp = misc[CM_TAIL_IP], tailOp = misc[CM_TAIL_OP], tailKind = misc[CM_TAIL_KIND];
+
+        if (nPar > 0u) {
+            uint4 *rk = (uint4 *)(tab + CU_TAB_RANK);
+            uint32_t *rkw = (uint32_t *)rk;
+            uint32_t *done = (uint32_t *)(tab + CU_TAB_DONE);
+            rk[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid == 0) rk[CU_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < CU_NMAX / 32) done[tid] = 0u;
+            __syncthreads();
+
+            // ---------------- 3. literals, and what a match takes from in front of the segment (global memory both) ----------------
+            for (uint32_t i = tid; i < nPar; i += CU_THREADS) {
+                const uint2 r = rec[i];
+                const uint32_t outStart = r.x & 0xffffu, litStart = r.x >> 16, lit = r.y & 0xffffu, off = r.y >> 16;
+                atomicOr(&rkw[4u * (outStart >> 6) + ((outStart >> 5) & 1u)], 1u << (outStart & 31u));
+                const uint32_t nextStart = rec[i + 1u].x & 0xffffu;
+                const uint32_t ml = nextStart - outStart - lit;
+                const LZ4_GLOBAL uint8_t *g = as_global(ssrc + litStart);
+                const uint32_t dA = A + outStart;
+                if (lit > 16u) {                                    // (at most 524)
+                    cu_lane_fetch(out, dA, g, lit);
+                } else if (lit > 8u) {
+                    // (a plain sequence ends 32 bytes before the staged bytes do: 16 bytes from its literals' start are there)
+                    const par_v4 v = *(const LZ4_GLOBAL par_v4u *)g;
+                    if (lit + ml >= 16u) {
+                        *(par_v4u *)&out[dA] = v;                  // the bytes past the literals fall into my own match area, written later
+                    } else {
+                        const uint64_t a = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                        const uint32_t sh = lit - 8u;              // 1..8: the last 8 literals start sh bytes in
+                        const uint32_t w1 = sh >= 4u ? v.y : v.x, w2 = sh >= 4u ? v.z : v.y, w3 = sh >= 4u ? v.w : v.z;
+                        const uint64_t b = (sh == 8u) ? ((uint64_t)v.z | ((uint64_t)v.w << 32))
+                                                      : ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh & 3u) |
+                                                         ((uint64_t)__builtin_amdgcn_alignbyte(w3, w2, sh & 3u) << 32));
+                        *(par_u64u *)&out[dA] = a;
+                        *(par_u64u *)&out[dA + sh] = b;
+                    }
+                } else if (lit > 0u) {
+                    const uint64_t v = *(const LZ4_GLOBAL par_u64u *)g;
+                    if (lit + ml >= 8u) {
+                        *(par_u64u *)&out[dA] = v;
+                    } else {
+                        uint64_t w = v;
+                        for (uint32_t q = 0; q < lit; q++) { out[dA + q] = (uint8_t)w; w >>= 8; }
+                    }
+                }
+                // A match whose source starts in front of the segment: those bytes are final in global memory (an earlier
+                // segment's output, or the dictionary: entirely, see `srcOk`).  They are fetched now -- behind my literals: a
+                // literal store may run over into my match area -- and the record's literal count grows by as much: what is left
+                // of the match, if anything, is a match whose source is the segment's first byte.
+                const int spos = (int)(outStart + lit) - (int)off;
+                if (spos < 0) {
+                    const uint32_t k = min(ml, (uint32_t)(-spos));
+                    const int sposBlk = opBase + spos;
+                    const LZ4_GLOBAL uint8_t *gs = as_global((DICT && sposBlk < 0) ? dictEnd + sposBlk : dst + sposBlk);
+                    cu_lane_fetch(out, dA + lit, gs, k);
+                    rec[i].y = (lit + k) | (off << 16);
+                }
+            }
+            __syncthreads();
+            stamp();                                              // [11] literals
+            // rank records: sequences that start before each group of 64 output positions
+            {
+                const uint4 w = rk[tid];
+                const uint32_t cnt = (uint32_t)__builtin_popcount(w.x) + (uint32_t)__builtin_popcount(w.y);
+                uint32_t tot;
+                const uint32_t pre = cu_scan_excl(cnt, scanTmp, &tot);
+                rkw[4u * tid + 2u] = pre;
+            }
+            __syncthreads();
+            stamp();                                              // [12] rank records
+
+            // ---------------- 4. matches ----------------
+            // index of the sequence that holds output position x
+            auto rank = [&](uint32_t x) -> uint32_t {
+                const uint4 r = rk[x >> 6];
+                const uint32_t m = (2u << (x & 31u)) - 1u;
+                const bool hi = (x & 32u) != 0u;
+                return r.z + (uint32_t)__builtin_popcount(r.x & (hi ? ~0u : m)) + (uint32_t)__builtin_popcount(r.y & (hi ? m : 0u)) - 1u;
+            };
+            // Every sequence's record becomes its match: {destination (LDS index) | length << 17, offset | wait << 16}, wait =
+            // first sequence its source overlaps (13 bits; 0x1fff: none, the source is literals of its own) | how many more
+            // (3 bits; 7: "up to the sequence in front of me").  A match that is complete already (length 0: all of it came
+            // from in front of the segment) sets its done bit here.  (All reads of the old records first, then the writes.)
+            {
+                uint32_t g0[CU_GENS], g1[CU_GENS];
+#pragma unroll
+                for (int g = 0; g < CU_GENS; g++) {
+                    const uint32_t i = (uint32_t)g * CU_THREADS + tid;
+                    g0[g] = 0u; g1[g] = 0u;
+                    if (i < nPar) {
+                        const uint2 r = rec[i];
+                        const uint32_t outStart = r.x & 0xffffu, lit = r.y & 0xffffu, off = r.y >> 16;
+                        const uint32_t nextStart = rec[i + 1u].x & 0xffffu;
+                        const uint32_t dpos = outStart + lit, ml = nextStart - dpos;
+                        const uint32_t spos = dpos - off;                     // (>= 0: what lay in front of the segment is in place)
+                        const uint32_t srcHi = min(spos + ml, outStart);      // bytes from outStart on are my own
+                        uint32_t code = 0x1fffu;
+                        if (ml != 0u && srcHi > spos) {
+                            const uint32_t jlo = rank(spos), span = rank(srcHi - 1u) - jlo;
+                            code = jlo | (min(span, 7u) << 13);
+                        }
+                        g0[g] = (A + dpos) | (ml << 17);
+                        g1[g] = off | (code << 16);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < CU_GENS; g++) {
+                    const uint32_t i = (uint32_t)g * CU_THREADS + tid;
+                    if (i < nPar) {
+                        rec[i] = make_uint2(g0[g], g1[g]);
+                        if ((g0[g] >> 17) == 0u) atomicOr(&done[i >> 5], 1u << (i & 31u));
+                    }
+                }
+                __syncthreads();
+            }
+            // The dependence graph is walked by CU_MWAVES waves; the others wait at the barrier.  A poll that finds nothing costs
+            // its wave's SIMD the same issue slots as one that does (a SIMD issues one wave-instruction in four cycles): with
+            // sixteen waves polling eight groups each, the few that had a copy to make got a quarter of their SIMD (measured:
+            // 1.5 us per level of the graph).  Wave w owns the 64-sequence groups w, w + CU_MWAVES, ... and works on CU_SLOTS of
+            // them at a time, in order (the graph is walked from the segment's start to its end; what becomes ready far ahead of
+            // that front loses nothing by waiting for a slot).  LDS operations of a wave execute in order and the LDS serves the
+            // CU's waves in arrival order, so a done bit set behind a copy's stores is seen behind them: no waits, only compiler
+            // fences.
+            if ((uint32_t)wave < CU_MWAVES) {
+                const uint32_t nGrp = (nPar + LZ4_WAVE - 1u) / LZ4_WAVE;      // 64-sequence groups in all; done[] words 2 grp, 2 grp + 1
+                uint32_t nextGrp = (uint32_t)wave;
+                uint32_t sg[CU_SLOTS], wlo[CU_SLOTS], whi[CU_SLOTS], f0[CU_SLOTS], f1[CU_SLOTS];
+                bool pd[CU_SLOTS];
+                auto load = [&](int sl) {
+                    sg[sl] = 0xffffffffu; pd[sl] = false; wlo[sl] = 1u; whi[sl] = 0u; f0[sl] = 0u; f1[sl] = 1u;
+                    while (nextGrp < nGrp && sg[sl] == 0xffffffffu) {
+                        const uint32_t i = nextGrp * LZ4_WAVE + (uint32_t)lane;
+                        bool mine = false;
+                        if (i < nPar) {
+                            const uint2 r = rec[i];
+                            f0[sl] = r.x; f1[sl] = r.y & 0xffffu;
+                            const uint32_t code = r.y >> 16, jlo = code & 0x1fffu, span = code >> 13;
+                            wlo[sl] = 1u; whi[sl] = 0u;
+                            if (jlo != 0x1fffu) { wlo[sl] = jlo; whi[sl] = (span == 7u) ? i - 1u : jlo + span; }
+                            mine = (r.x >> 17) != 0u;
+                        }
+                        pd[sl] = mine;
+                        if (__ballot(mine)) sg[sl] = nextGrp;           // (a group with nothing left to copy is skipped)
+                        nextGrp += CU_MWAVES;
+                    }
+                    if (sg[sl] == 0xffffffffu) pd[sl] = false;
+                };
+#pragma unroll
+                for (int sl = 0; sl < CU_SLOTS; sl++) load(sl);
+                uint32_t idle = 0, nIter = 0, nProg = 0;
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int sl = 0; sl < CU_SLOTS; sl++) any = any || sg[sl] != 0xffffffffu;
+                    if (!any) break;
+                    nIter++;
+                    // ---- poll: the slots' done words, and -- behind them, in the same batch -- the first 32 bytes of every pending
+                    // match's source.  LDS reads of a wave execute in order: if the done word shows the sources complete, the bytes
+                    // read behind it are final; if not, they are dropped.  One round trip per poll instead of two. ----
+                    uint32_t dw[CU_SLOTS];
+                    uint32_t d[CU_SLOTS], sA[CU_SLOTS], off[CU_SLOTS], ml[CU_SLOTS];
+                    bool g16[CU_SLOTS], g8[CU_SLOTS], g4[CU_SLOTS];
+                    par_v4 v0[CU_SLOTS], v1[CU_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < CU_SLOTS; sl++) {
+                        dw[sl] = 0u;
+                        if (pd[sl] && wlo[sl] <= whi[sl]) dw[sl] = __atomic_load_n(&done[wlo[sl] >> 5], __ATOMIC_RELAXED);
+                        d[sl] = f0[sl] & 0x1ffffu; ml[sl] = pd[sl] ? f0[sl] >> 17 : 0u; off[sl] = pd[sl] ? f1[sl] : 1u;
+                        sA[sl] = d[sl] - off[sl];
+                        // the classes are decode_par.hpp's (step 7): chunks that never read their own writes; one 16-byte read serves
+                        // every class (the bytes past a short match are read and dropped, the short classes' second chunk is cut out
+                        // of it in registers)
+                        const bool w8 = ml[sl] >= 8u && off[sl] >= 8u;
+                        const bool grp = w8 && (off[sl] >= 32u || off[sl] >= ml[sl]);
+                        g16[sl] = grp && ml[sl] >= 16u;
+                        g8[sl] = grp && ml[sl] < 16u;
+                        g4[sl] = ml[sl] >= 4u && ml[sl] < 8u && off[sl] >= ml[sl];
+                        v0[sl] = (par_v4){0u, 0u, 0u, 0u}; v1[sl] = v0[sl];
+                        if (g16[sl] || g8[sl] || g4[sl]) v0[sl] = *(const par_v4u *)&out[sA[sl]];
+                        if (g16[sl] && ml[sl] > 16u) v1[sl] = *(const par_v4u *)&out[sA[sl] + min(16u, ml[sl] - 16u)];
+                    }
+                    // ---- which of my sequences are ready ----
+                    bool ready[CU_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < CU_SLOTS; sl++) {
+                        ready[sl] = false;
+                        if (pd[sl]) {
+                            const uint32_t lo = wlo[sl], hi = whi[sl];
+                            if (lo > hi) ready[sl] = true;
+                            else {
+                                const bool last = (hi >> 5) == (lo >> 5);
+                                const uint32_t hiB = last ? (hi & 31u) : 31u;
+                                const uint32_t m = ((2u << hiB) - 1u) & ~((1u << (lo & 31u)) - 1u);
+                                const uint32_t miss = ~dw[sl] & m;
+                                if (miss) wlo[sl] = (lo & ~31u) + (uint32_t)__builtin_ctz(miss);
+                                else if (last) ready[sl] = true;
+                                else wlo[sl] = (lo | 31u) + 1u;
+                            }
+                        }
+                    }
+                    uint64_t rm[CU_SLOTS];
+                    bool progress = false;
+#pragma unroll
+                    for (int sl = 0; sl < CU_SLOTS; sl++) { rm[sl] = __ballot(ready[sl]); progress = progress || rm[sl] != 0ull; }
+                    if (progress) {
+                        bool slow[CU_SLOTS];
+#pragma unroll
+                        for (int sl = 0; sl < CU_SLOTS; sl++) {
+                            g16[sl] = g16[sl] && ready[sl]; g8[sl] = g8[sl] && ready[sl]; g4[sl] = g4[sl] && ready[sl];
+                            slow[sl] = ready[sl] && !(g16[sl] || g8[sl] || g4[sl]);
+                            if (g16[sl]) {
+                                *(par_v4u *)&out[d[sl]] = v0[sl];
+                                if (ml[sl] > 16u) *(par_v4u *)&out[d[sl] + min(16u, ml[sl] - 16u)] = v1[sl];
+                            }
+                            const uint32_t sh = ml[sl] - 8u;                                  // g8: 0..7
+                            const bool up = (sh & 4u) != 0u;
+                            const uint32_t lo = up ? v0[sl].y : v0[sl].x, mid = up ? v0[sl].z : v0[sl].y, hi = up ? v0[sl].w : v0[sl].z;
+                            if (g8[sl]) {
+                                *(par_u64u *)&out[d[sl]] = (uint64_t)v0[sl].x | ((uint64_t)v0[sl].y << 32);
+                                *(par_u64u *)&out[d[sl] + sh] = (uint64_t)__builtin_amdgcn_alignbyte(mid, lo, sh & 3u) |
+                                                                ((uint64_t)__builtin_amdgcn_alignbyte(hi, mid, sh & 3u) << 32);
+                            }
+                            if (g4[sl]) {
+                                *(par_u32u *)&out[d[sl]] = v0[sl].x;
+                                *(par_u32u *)&out[d[sl] + ml[sl] - 4u] = __builtin_amdgcn_alignbyte(v0[sl].y, v0[sl].x, (ml[sl] - 4u) & 3u);
+                            }
+                        }
+                        // matches longer than 32 bytes: 32 more per step (both reads of a step before its writes)
+                        for (uint32_t base = 32u;; base += 32u) {
+                            bool more = false;
+#pragma unroll
+                            for (int sl = 0; sl < CU_SLOTS; sl++) more = more || (g16[sl] && base < ml[sl]);
+                            if (!__ballot(more)) break;
+                            par_v4 a[CU_SLOTS], b[CU_SLOTS];
+                            uint32_t o0[CU_SLOTS], o1[CU_SLOTS];
+#pragma unroll
+                            for (int sl = 0; sl < CU_SLOTS; sl++) {
+                                const bool on = g16[sl] && base < ml[sl];
+                                o0[sl] = min(base, ml[sl] - 16u); o1[sl] = min(base + 16u, ml[sl] - 16u);
+                                a[sl] = (par_v4){0u, 0u, 0u, 0u}; b[sl] = a[sl];
+                                if (on) { a[sl] = *(const par_v4u *)&out[sA[sl] + o0[sl]]; b[sl] = *(const par_v4u *)&out[sA[sl] + o1[sl]]; }
+                            }
+#pragma unroll
+                            for (int sl = 0; sl < CU_SLOTS; sl++)
+                                if (g16[sl] && base < ml[sl]) { *(par_v4u *)&out[d[sl] + o0[sl]] = a[sl]; *(par_v4u *)&out[d[sl] + o1[sl]] = b[sl]; }
+                        }
+                        // the rest (matches that overlap their own output, what is left of a match shorter than four bytes) one
+                        // after the other by the whole wave
+#pragma unroll
+                        for (int sl = 0; sl < CU_SLOTS; sl++)
+                            for (uint64_t sm = __ballot(slow[sl]); sm; sm &= sm - 1ull) {
+                                const int k = (int)__builtin_ctzll(sm);
+                                cu_wave_copy(out, (uint32_t)__builtin_amdgcn_readlane((int)d[sl], k), (uint32_t)__builtin_amdgcn_readlane((int)sA[sl], k),
+                                             (uint32_t)__builtin_amdgcn_readlane((int)off[sl], k), (uint32_t)__builtin_amdgcn_readlane((int)ml[sl], k));
+                            }
+                        wave_fence();
+                        if (lane == 0) {
+#pragma unroll
+                            for (int sl = 0; sl < CU_SLOTS; sl++) {
+                                if ((uint32_t)rm[sl]) atomicOr(&done[2u * sg[sl]], (uint32_t)rm[sl]);
+                                if ((uint32_t)(rm[sl] >> 32)) atomicOr(&done[2u * sg[sl] + 1u], (uint32_t)(rm[sl] >> 32));
+                            }
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < CU_SLOTS; sl++) {
+                            if (ready[sl]) pd[sl] = false;
+                            if (sg[sl] != 0xffffffffu && !__ballot(pd[sl])) load(sl);
+                        }
+                    }
+                    if (!progress) {
+                        // Every wait is for a sequence with a smaller index, and the group that holds it is in a slot or done
+                        // (groups enter slots in order): some wave always makes progress; the limit only guarantees that a launch
+                        // ends whatever state its tables are in (the block is then decoded again)
+                        if (++idle > CU_IDLE_LIMIT) { if (lane == 0) __atomic_store_n(&misc[CM_ABORT], 1u, __ATOMIC_RELAXED); }
+                        if (__atomic_load_n(&misc[CM_ABORT], __ATOMIC_RELAXED)) break;
+                    } else { idle = 0; nProg++; }
+                }
+                if (dbg && tid == 0 && seg == 0) dbg[3] = (nIter << 16) | (nProg & 0xffffu);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (misc[CM_ABORT] != 0u) { redo = true; why = 4; }
+            stamp();                                              // [13] matches
+            if (redo) break;
+
+            // ---------------- 5. flush the segment's output [0, tailOp) ----------------
+            {
+                LZ4_GLOBAL uint8_t *gd = as_global(sdst);
+                const uint32_t total = A + tailOp;
+                for (uint32_t k = tid; k < total / 16u; k += CU_THREADS)
+                    if (k > 0u || A == 0u) *(LZ4_GLOBAL par_v4 *)(gd + 16u * k - A) = *(const par_v4 *)&out[16u * k];
+                if (A != 0u && tid < 16u - A && tid < tailOp) gd[tid] = out[A + tid];
+                for (uint32_t x = (total / 16u) * 16u + tid; x < total; x += CU_THREADS)
+                    if (x >= A && (x >= 16u || A == 0u)) gd[x - A] = out[x];
+            }
+        }
+        // ---------------- 6. what comes next ----------------
+        __threadfence_block();
+        __syncthreads();                                          // (the segment's output is in global memory; nobody reads misc[] or the LDS output any more)
+        ipBase += (int)tailIp; opBase += (int)tailOp;
+        if (seg == 0) { dbgAt = 14; stamp(); }                    // [14] flushed
+        // a sequence the parse does not take, or a segment that took nothing: one sequence by the sequential decoder
+        if (tailKind == 1u || nPar == 0u) seqMode = 1;
+    }
+    __syncthreads();
+    if (redo) result = CU_REDO;
+    dbgAt = 15;
+    stamp();                                                     // [15] end
+    if (dbg && tid == 0) { dbg[0] = why; dbg[2] = (uint32_t)clock64() - cyc0; }
+    return result;
+}
+
+} // namespace lz4dev

@@ -68,6 +68,8 @@ struct DecodeArgs {
     // blockOff[blk] / 2 (a sequence is at least three compressed bytes), tokCnt[blk] entries; both null without the list pass
     uint8_t *tokList;
     int32_t *tokCnt;
+    // diagnostics of the workgroup-per-block decoder (mi355lz4_debug_cu): 16 words per block, null = off
+    uint32_t *cuDbg;
 };
 
 struct EncodeArgs {
@@ -101,6 +103,7 @@ struct EncodeSegArgs {
 void launch_encode_seg(const EncodeSegArgs &a, hipStream_t s);
 void launch_decode_seq(const DecodeArgs &a, hipStream_t s);
 void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream_t s);
+void launch_decode_cu(const DecodeArgs &a, hipStream_t s);       // one workgroup per block (decode_cu.hpp): calls that do not fill the GPU
 #ifdef MI355LZ4_EXPERIMENTS
 void launch_decode_tok(const DecodeArgs &a, hipStream_t s);      // token lists (a.tokList / a.tokCnt), then the list-driven decoder
 #endif

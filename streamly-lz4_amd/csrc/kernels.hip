@@ -15,6 +15,7 @@
 
 #include "decode_seq.hpp"
 #include "decode_par.hpp"
+#include "decode_cu.hpp"
 #include "linked_replay.hpp"
 #include "linked_ptr.hpp"
 #include "encode_wave.hpp"
@@ -535,6 +536,46 @@ void launch_decode_par(const DecodeArgs &a, unsigned long long *stats, hipStream
         hipLaunchKernelGGL(k_decode_par<true>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
     else
         hipLaunchKernelGGL(k_decode_par<false>, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a, stats);
+    launch_link_stat(a, s);
+}
+
+// The blocks the workgroup-per-block decoder left behind (result CU_REDO), by the lane-parallel decoder.  (A kernel of its
+// own, not a template parameter of k_decode_par: that changed the headline kernel's register allocation.)
+__global__ PAR_OCC void k_decode_par_redo(DecodeArgs a)
+{
+    __shared__ ParLds lds;
+    const int blk = (int)blockIdx.x;
+    if (uni(a.result[blk]) != CU_REDO) return;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = read_block_header(a, blk, data, compLen, cap);
+    if (r == 0)
+        // (LIST with an empty list: the same decoder as k_decode_par's, but an instantiation of its own -- a second user of
+        // k_decode_par's instantiation turns that kernel's inlined decoder into a call)
+        r = decode_block_par<false, false, false, true>(data, compLen, a.out + a.outOff[blk], cap, nullptr, 0, a.framed,
+                                                        a.framed + a.framedLen, lds, nullptr, nullptr, nullptr, 0);
+    if (lane_id() == 0) a.result[blk] = r;
+}
+
+// Workgroup-per-block decoder (decode_cu.hpp): sixteen wavefronts per block, for calls that do not fill the GPU.
+__global__ __launch_bounds__(CU_THREADS) void k_decode_cu(DecodeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[CU_LDS_BYTES];
+    const int blk = (int)blockIdx.x;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = uni(read_block_header(a, blk, data, compLen, cap));
+    if (r == 0)
+        r = decode_block_cu<false>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), nullptr, 0, a.framed, a.framed + a.framedLen, lds,
+                                   a.cuDbg ? a.cuDbg + 16 * (size_t)blk : nullptr);
+    if (threadIdx.x == 0) a.result[blk] = r;
+}
+
+void launch_decode_cu(const DecodeArgs &a, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    hipLaunchKernelGGL(k_decode_cu, dim3((unsigned)a.nBlocks), dim3(CU_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_decode_par_redo, dim3((unsigned)a.nBlocks), dim3(64), 0, s, a);
     launch_link_stat(a, s);
 }
 

@@ -155,6 +155,8 @@ DECLARED_SYMBOLS = [
     "mi355lz4_decompress_linked_end", "mi355lz4_decompress_linked_end_last", "mi355lz4_index_device", "mi355lz4_compress_batch", "mi355lz4_index_host",
     "mi355lz4_decompress_batch", "mi355lz4_decompress_streams", "mi355lz4_generate_device", "mi355lz4_interleave_device", "mi355lz4_event_create",
     "mi355lz4_event_destroy", "mi355lz4_event_record", "mi355lz4_event_elapsed_ms",
+    "mi355lz4_create_multi", "mi355lz4_destroy_multi", "mi355lz4_multi_device_count", "mi355lz4_multi_engine", "mi355lz4_multi_last_error",
+    "mi355lz4_multi_compress_batch", "mi355lz4_multi_decompress_batch",
     "LZ4_createStream", "LZ4_freeStream", "LZ4_createStreamDecode", "LZ4_freeStreamDecode", "LZ4_compressBound",
     "LZ4_compress_fast_continue", "LZ4_decompress_safe_continue",
 ]
@@ -245,6 +247,79 @@ class Event:
                 lib.mi355lz4_event_destroy(self.h)
         except Exception:
             pass
+
+
+class MultiEngine:
+    """Several GPUs behind one handle, one process (include/mi355lz4.h, "several GPUs behind one handle"): the host-buffer
+    calls of Engine with the batch cut into one contiguous block range per device.  devices: list of HIP device ordinals
+    (the same one may be named more than once: two engines on one GPU)."""
+
+    def __init__(self, devices):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = lib.mi355lz4_create_multi(C.byref(self._h), arr, len(devices))
+        if rc != 0:
+            lib.mi355lz4_multi_last_error.restype = C.c_char_p
+            raise LZ4Error("create_multi failed (%d): %s" % (rc, (lib.mi355lz4_multi_last_error() or b"").decode()))
+        self.n = len(devices)
+
+    def close(self):
+        if self._h:
+            lib.mi355lz4_destroy_multi(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, rc, what, allow_block_error):
+        if rc != 0 and not (allow_block_error and rc == -5):
+            lib.mi355lz4_multi_last_error.restype = C.c_char_p
+            raise LZ4Error("%s failed (%d): %s" % (what, rc, (lib.mi355lz4_multi_last_error() or b"").decode()))
+
+    def set_decoder(self, variant):
+        lib.mi355lz4_multi_engine.restype = C.c_void_p
+        for i in range(self.n):
+            _check(lib.mi355lz4_set_decoder(C.c_void_p(lib.mi355lz4_multi_engine(self._h, i)), int(variant)), "set_decoder")
+
+    def compress_batch(self, blocks, accel=1, header_kind=8):
+        """blocks: list of bytes-like.  Returns (framed bytes, [framed length per block])."""
+        n = len(blocks)
+        arrs = [np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b for b in blocks]
+        ptrs = (_u8p * max(n, 1))(*[a.ctypes.data_as(_u8p) for a in arrs])
+        lens = np.array([a.size for a in arrs], dtype=np.int32)
+        cap = int(sum(compress_bound(int(x)) + header_kind for x in lens)) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_size_t()
+        flen = np.zeros(max(n, 1), dtype=np.int32)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        rc = lib.mi355lz4_multi_compress_batch(self._h, ptrs, lens.ctypes.data_as(_i32p), n, int(accel), int(header_kind),
+                                               out.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(out_len),
+                                               flen.ctypes.data_as(_i32p), status.ctypes.data_as(_i32p))
+        self._raise(rc, "multi_compress_batch", False)
+        return out[: out_len.value].tobytes(), flen[:n].tolist()
+
+    def decompress_batch(self, framed, header_kind=8, fixed_uncomp=0, raise_on_block_error=True):
+        """Returns (decoded bytes, [decoded length or negative code per block])."""
+        src = np.frombuffer(bytes(framed), dtype=np.uint8)
+        max_blocks = src.size // (header_kind + 1) + 1
+        boff = np.zeros(max_blocks + 1, dtype=np.uint64)
+        ulen = np.zeros(max_blocks + 1, dtype=np.int32)
+        nb = C.c_int()
+        _check(lib.mi355lz4_index_host(src.ctypes.data_as(_u8p), src.size, header_kind, fixed_uncomp,
+                                       boff.ctypes.data_as(_u64p), ulen.ctypes.data_as(_i32p), max_blocks, C.byref(nb)), "index_host")
+        cap = int(ulen[: nb.value].astype(np.int64).clip(min=0).sum()) + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_size_t()
+        blen = np.zeros(max(nb.value, 1), dtype=np.int32)
+        got = C.c_int()
+        rc = lib.mi355lz4_multi_decompress_batch(self._h, src.ctypes.data_as(_u8p), C.c_size_t(src.size), header_kind, fixed_uncomp,
+                                                 out.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(out_len),
+                                                 blen.ctypes.data_as(_i32p), max(nb.value, 1), C.byref(got))
+        self._raise(rc, "multi_decompress_batch", not raise_on_block_error)
+        return out[: out_len.value].tobytes(), blen[: got.value].tolist()
 
 
 class Engine:

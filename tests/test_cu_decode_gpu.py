@@ -1,0 +1,154 @@
+"""The workgroup-per-block decoder (decoder variant 4, csrc/decode_cu.hpp; what variant 0 picks for calls of up to 256
+independent blocks): the same bytes and the same per-block results -- the reference's negative codes included
+(cbits/lz4.c:2163) -- as the lane-parallel decoder and the oracle, on the shapes that move it between its forms:
+blocks of several segments (more than 64 KiB of output or 42 KiB of compressed bytes), lengths with one, two and many
+extension bytes (the parse follows two), long literal stretches inside compressible data, matches that overlap their own
+output, sources in front of a segment, tiny blocks (left to the lane-parallel decoder), corrupted blocks."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame_ref(oracle, blocks):
+    """independent blocks written by the oracle (= the reference's bytes), 8-byte headers"""
+    out = []
+    for b in blocks:
+        c = oracle.compress_block(b, 1)
+        out.append(len(c).to_bytes(4, "little") + len(b).to_bytes(4, "little") + c)
+    return b"".join(out)
+
+
+def _both(engine, framed, expect=None, what=""):
+    res = {}
+    try:
+        for v in (2, 4):
+            engine.set_decoder(v)
+            res[v] = engine.decompress_batch(framed, raise_on_block_error=False)
+    finally:
+        engine.set_decoder(0)
+    assert res[2][1] == res[4][1], (what, [(i, a, b) for i, (a, b) in enumerate(zip(res[2][1], res[4][1])) if a != b][:8])
+    if res[2][0] != res[4][0]:
+        a, b = np.frombuffer(res[2][0], np.uint8), np.frombuffer(res[4][0], np.uint8)
+        raise AssertionError((what, "bytes differ at", np.nonzero(a != b)[0][:8].tolist()))
+    if expect is not None:
+        assert res[4][0] == expect, what
+    return res[4]
+
+
+@pytest.mark.parametrize("kind", ["lzsynth", "text", "random"])
+def test_cu_decoder_full_blocks(engine, oracle, kind):
+    raw = oracle.gen(kind, 24, 65536, first_block=100).tobytes()
+    blocks = [raw[i:i + 65536] for i in range(0, len(raw), 65536)]
+    _both(engine, _frame_ref(oracle, blocks), raw, kind + " reference-written")
+    _both(engine, engine.compress_batch(blocks)[0], raw, kind + " engine-written")
+    # the decoder a call of this size gets by default is this one: same answer
+    out, blen = engine.decompress_batch(_frame_ref(oracle, blocks))
+    assert out == raw and blen == [65536] * 24
+
+
+def test_cu_decoder_odd_shapes(engine, oracle):
+    from test_fuzz_encode_gpu import _make
+    rng = random.Random(7)
+    blocks = [_make(rng, oracle, t) for t in range(200)]
+    text = oracle.gen("text", 1, 30000).tobytes()
+    blocks += [bytes(65536), bytes(40000), b"ab" * 30000, bytes(range(256)) * 200, oracle.gen("text", 1, 70000).tobytes(),
+               text + oracle.gen("random", 1, 5000).tobytes() + oracle.gen("text", 1, 30000, first_block=9).tobytes(),   # a literal run of 5000 inside text
+               text[:9000] + oracle.gen("random", 1, 400).tobytes() + text[9000:],                                            # ... of 400 (two extension bytes)
+               text[:20000] + text[1000:1500] + text[20000:],                                                                  # a match of 500
+               oracle.gen("lzsynth", 1, 262144).tobytes(), oracle.gen("text", 1, 1 << 20, first_block=3).tobytes(),
+               oracle.gen("random", 1, 100000).tobytes(), oracle.gen("text", 1, 1000).tobytes(), b"", b"x",
+               oracle.gen("text", 1, 65535).tobytes(), (oracle.gen("text", 1, 3000).tobytes() + bytes(1500)) * 14]
+    raw = b"".join(blocks)
+    _both(engine, _frame_ref(oracle, blocks), raw, "odd shapes, reference-written")
+    _both(engine, engine.compress_batch(blocks)[0], raw, "odd shapes, engine-written")
+
+
+def test_cu_decoder_big_blocks(engine, oracle):
+    """BlockMax1MB / BlockMax4MB sized blocks (Config.hs:109-116): 16 and 64 segments a block, sources in earlier segments."""
+    for n, kind in ((1 << 20, "text"), (4 << 20, "lzsynth"), ((4 << 20) - 7, "text")):
+        data = oracle.gen(kind, (n + 65535) // 65536, 65536, first_block=11).tobytes()[:n]
+        # text repeats itself across the block: matches reach back up to 65535 bytes, into earlier segments
+        fr = _frame_ref(oracle, [data, data[: n // 3]])
+        _both(engine, fr, data + data[: n // 3], "big blocks %d %s" % (n, kind))
+
+
+def test_cu_decoder_corrupted_blocks(engine, oracle):
+    rng = random.Random(5)
+    base = [oracle.gen("text", 1, 65536, first_block=5).tobytes(), oracle.gen("lzsynth", 1, 65536, first_block=6).tobytes(),
+            oracle.gen("text", 1, 200000, first_block=8).tobytes()]
+    nbad = 0
+    for trial in range(240):
+        b = base[trial % 3]
+        c = bytearray(oracle.compress_block(b, 1))
+        for _ in range(rng.choice((1, 1, 2, 5))):
+            pos = rng.randrange(len(c)) if trial % 4 else rng.randrange(max(1, len(c) - 200), len(c))
+            c[pos] = rng.choice((rng.randrange(256), 0xFF, 0x00))
+        cl = len(c) if trial % 7 else len(c) - rng.randrange(1, 40)
+        ul = len(b) if trial % 5 else len(b) - rng.randrange(0, 300)
+        fr = cl.to_bytes(4, "little") + ul.to_bytes(4, "little") + bytes(c[:cl])
+        out, blen = _both(engine, fr, None, "corrupted %d" % trial)
+        code, want = oracle.decompress_block(bytes(c[:cl]), ul)
+        assert blen == [code], (trial, blen, code)
+        if code >= 0:
+            assert out == want
+        nbad += code < 0
+    assert nbad > 40
+
+
+def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
+    """Variant 0: up to 256 blocks a call go to the workgroup-per-block decoder, more to the lane-parallel one (its 16 words
+    of diagnostics per block tell which ran); a linked call always takes the lane-parallel decoder."""
+    import ctypes as C
+    import torch
+    S = pytest.importorskip("streamly_lz4_amd")
+    dev = torch.device("cuda:0")
+    for nblk, linked, expect in ((100, False, True), (256, False, True), (257, False, False), (100, True, False)):
+        raw = oracle.gen("text", nblk, 4096, first_block=1).tobytes()
+        blocks = [raw[i:i + 4096] for i in range(0, len(raw), 4096)]
+        fr = _frame_ref(oracle, blocks)
+        offs, pos = [], 0
+        for _ in range(nblk):
+            offs.append(pos)
+            pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+        buf = torch.frombuffer(bytearray(fr), dtype=torch.uint8).to(dev)
+        boff = torch.tensor(offs + [pos], dtype=torch.int64, device=dev)
+        ooff = torch.arange(0, (nblk + 1) * 4096, 4096, dtype=torch.int64, device=dev)
+        out = torch.zeros(nblk * 4096, dtype=torch.uint8, device=dev)
+        res = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        dbg = torch.zeros(nblk * 16, dtype=torch.int32, device=dev)
+        S.lib.mi355lz4_debug_cu(engine.ctx, C.c_void_p(dbg.data_ptr()))
+        try:
+            engine.decompress_batch_device(buf, len(fr), boff, nblk, out, ooff, res, linked=linked)
+            engine.synchronize()
+        finally:
+            S.lib.mi355lz4_debug_cu(engine.ctx, None)
+        assert out.cpu().numpy().tobytes() == raw and bool((res == 4096).all())
+        ran = bool((dbg.view(nblk, 16)[:, 15] != 0).any().item())       # [15]: the clock at the block's end
+        assert ran == expect, (nblk, linked, ran)
+
+
+def test_runin_state_decays_with_every_linked_call(engine, oracle):
+    """The run-in decode's adaptive state (api.cpp: runinLong, runinLongOk, runinSkip): an engine that was sent to the long run-in
+    tries the default again after RUNIN_LONG_PROBE (32) linked calls of ANY size, not only after that many long run-ins."""
+    import ctypes as C
+    S = pytest.importorskip("streamly_lz4_amd")
+    f = S.lib.mi355lz4_debug_runin_state
+    f.restype = C.c_int
+    st = (C.c_int * 3)()
+    data = oracle.gen("text", 8, 65536).tobytes()
+    fr = oracle.frame_compress(data, 65536, 1, 8, True)                 # a linked stream far below every run-in threshold
+    try:
+        assert f(engine.ctx, None, (C.c_int * 3)(1, 0, 0)) == 0         # as if a call had been given up with the default run-in
+        for k in range(31):
+            out, _ = engine.decompress_batch(fr, linked=True)
+            assert out == data
+            f(engine.ctx, st, None)
+            assert list(st) == [1, k + 1, 0], (k, list(st))
+        out, _ = engine.decompress_batch(fr, linked=True)
+        f(engine.ctx, st, None)
+        assert out == data and list(st) == [0, 0, 0]
+    finally:
+        f(engine.ctx, None, (C.c_int * 3)(0, 0, 0))

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("decoder", [2, 1])
+@pytest.mark.parametrize("decoder", [2, 1, 4])
 def test_fuzz_large_blocks(engine, oracle, decoder):
     import torch
     dev = torch.device("cuda:0")

@@ -514,7 +514,7 @@ def test_decode_config2_reference_written_256MiB(engine, oracle, kind):
     fr = oracle.frame_compress(data, bl, 1, 8, False)
     want = sha(data)
     try:
-        for decoder in (1, 2):
+        for decoder in (1, 2, 4):
             engine.set_decoder(decoder)
             out, blen = engine.decompress_batch(fr)
             assert blen == [bl] * nb, (kind, decoder)
@@ -553,8 +553,8 @@ def test_ragged_batch_roundtrip(engine, oracle):
         assert int.from_bytes(fr[pos + 4:pos + 8], "little") == len(b)
         assert oracle.decompress_block(fr[pos + 8:pos + f], len(b)) == (len(b), b)
         pos += f
-    # and the GPU decodes the whole ragged stream, both kernels
-    for dec in (1, 2):
+    # and the GPU decodes the whole ragged stream, every kernel
+    for dec in (1, 2, 4):
         engine.set_decoder(dec)
         out, blen = engine.decompress_batch(fr)
         assert blen == [len(b) for b in blocks] and out == b"".join(blocks)
