@@ -676,6 +676,19 @@ def main():
         indep = [codec.compress_block(b, accel) for b in blocks]
         cpu["decode_reference_written_independent"] = reference_stream_decode(S, eng, torch, dev, indep, src, ns, BL, linked=False)
         del indep
+        # ... and, for a like-for-like reading of that figure, the ENGINE's own stream of the same sample in a call of the same
+        # size: a call of 16 384 blocks decodes 10 % slower than `value`'s 65 536 whoever wrote it (the last waves of a launch
+        # run on a GPU that is emptying), the writer is worth about 1 % (scripts/par_stats_ref.py)
+        if dom == "decompress" and ns < NB:
+            e0, e1 = S.Event(), S.Event()
+            best = 1e9
+            for _ in range(3):
+                eng.record(e0)
+                eng.decompress_batch_device(dense, gpu_sample_bytes, doff, ns, out, ooff, res)
+                eng.record(e1)
+                eng.synchronize()
+                best = min(best, eng.elapsed_ms(e0, e1))
+            cpu["decode_reference_written_independent"]["engine_written_same_sample_GBps"] = round(ns * BL / best / 1e6, 2)
         if not args.no_cpu_all_cores:
             # best-case CPU, NOT reference behaviour (its API is one serial stream): one independent
             # linked context per host thread over contiguous block ranges of the same sample

@@ -345,42 +345,49 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 for (int j = 0; j < 8; j++) W[j] = wp[j];
                 W[8] = *(const uint32_t *)(comp + cu_at(base + 32u));
             }
-            uint32_t S[CU_CHUNK];
+            // (the chunk's upper half first, then the lower: the backward pass of the lower half finds the upper half's entries in
+            // LDS like everything else it looks up, and sixteen successors are live at a time instead of thirty-two)
 #pragma unroll
-            for (int k = 0; k < CU_CHUNK; k++) {
-                const uint32_t p = base + (uint32_t)k;
-                const uint32_t t = (W[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                const uint32_t b1 = (W[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu;
-                const uint32_t b1b = (W[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu;
-                uint32_t lit, litBytes;
-                bool bad;
-                cu_lit(t, b1, b1b, lit, litBytes, bad);
-                uint32_t nxt = p + 3u + litBytes + lit;
-                if ((t & 15u) == 15u) {                             // the match length's extension byte(s)
-                    nxt++;
-                    const uint32_t b2 = comp[cu_at(min(nxt - 1u, inLim))];
-                    if (b2 == 255u) { bad = bad || comp[cu_at(min(nxt, inLim))] == 255u; nxt++; }
+            for (int half = 1; half >= 0; half--) {
+                uint32_t S[CU_CHUNK / 2];
+#pragma unroll
+                for (int kk = 0; kk < CU_CHUNK / 2; kk++) {
+                    const int k = 16 * half + kk;
+                    const uint32_t p = base + (uint32_t)k;
+                    const uint32_t t = (W[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    const uint32_t b1 = (W[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu;
+                    const uint32_t b1b = (W[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu;
+                    uint32_t lit, litBytes;
+                    bool bad;
+                    cu_lit(t, b1, b1b, lit, litBytes, bad);
+                    uint32_t nxt = p + 3u + litBytes + lit;
+                    if ((t & 15u) == 15u) {                             // the match length's extension byte(s)
+                        nxt++;
+                        const uint32_t b2 = comp[cu_at(min(nxt - 1u, inLim))];
+                        if (b2 == 255u) { bad = bad || comp[cu_at(min(nxt, inLim))] == 255u; nxt++; }
+                    }
+                    S[kk] = (!bad && p < plim && nxt <= inLim) ? nxt : CU_STOP;
                 }
-                S[k] = (!bad && p < plim && nxt <= inLim) ? nxt : CU_STOP;
-            }
-            // backwards, three positions at a time (k = 31, 30, 29; 28, 27, 26; ...; 1, 0)
+                // backwards, three positions at a time (kk = 15, 14, 13; 12, 11, 10; ...; 0)
 #pragma unroll
-            for (int g = CU_CHUNK - 1; g >= 0; g -= 3) {
-                uint32_t r[3];
+                for (int g = CU_CHUNK / 2 - 1; g >= 0; g -= 3) {
+                    uint32_t r[3];
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int k = g - j;
-                    r[j] = CU_STOP;
-                    if (k >= 0 && S[k < 0 ? 0 : k] < cend) r[j] = T_at(S[k < 0 ? 0 : k]);
-                }
+                    for (int j = 0; j < 3; j++) {
+                        const int kk = g - j;
+                        r[j] = CU_STOP;
+                        if (kk >= 0 && S[kk < 0 ? 0 : kk] < cend) r[j] = T_at(S[kk < 0 ? 0 : kk]);
+                    }
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const int k = g - j;
-                    if (k >= 0) {
-                        const uint32_t p = base + (uint32_t)k;
-                        const uint32_t sv = (S[k] < cend) ? r[j] : S[k];
-                        Tt[(uint32_t)k * NCH + c] = (uint16_t)sv;
-                        if (sv != CU_STOP && (sv / CU_SUPER) != (p / CU_SUPER)) atomicOr(&cbits[sv >> 5], 1u << (sv & 31u));
+                    for (int j = 0; j < 3; j++) {
+                        const int kk = g - j;
+                        if (kk >= 0) {
+                            const int k = 16 * half + kk;
+                            const uint32_t p = base + (uint32_t)k;
+                            const uint32_t sv = (S[kk] < cend) ? r[j] : S[kk];
+                            Tt[(uint32_t)k * NCH + c] = (uint16_t)sv;
+                            if (sv != CU_STOP && (sv / CU_SUPER) != (p / CU_SUPER)) atomicOr(&cbits[sv >> 5], 1u << (sv & 31u));
+                        }
                     }
                 }
             }

@@ -51,11 +51,13 @@ def test_multi_handle_matches_single_engine(slz4, engine, oracle, ndev):
 def test_multi_handle_reports_a_failing_block_in_its_place(slz4, engine, oracle):
     blocks = [oracle.gen("text", 1, 65536, first_block=k).tobytes() for k in range(12)]
     fr, flen = engine.compress_batch(blocks)
-    bad = bytearray(fr)
-    pos = sum(flen[:7])
-    for k in range(40):
-        bad[pos + 8 + 300 + k] = 0xFF                                          # block 7 (in the second of two ranges / third of three)
-    want = engine.decompress_batch(bytes(bad), raise_on_block_error=False)[1]
+    pos = sum(flen[:7])                                                        # block 7 (in the second of two ranges / third of three)
+    for start in range(300, 6000, 97):
+        bad = bytearray(fr)
+        bad[pos + 8 + start:pos + 8 + start + 64] = b"\xff" * 64
+        want = engine.decompress_batch(bytes(bad), raise_on_block_error=False)[1]
+        if want[7] < 0:
+            break
     assert want[7] < 0 and all(w == 65536 for i, w in enumerate(want) if i != 7)
     for ndev in (2, 3):
         m = slz4.MultiEngine([0] * ndev)
