@@ -398,22 +398,21 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         // ---------------- 2b. candidates of every super-chunk, and where each leaves it ----------------
         // the j-th candidate (set bit) of super-chunk k in a bit vector with one word per chunk; *total = how many it has
         auto nth_cand = [&](const uint32_t *bitsOf, uint32_t k, uint32_t j, uint32_t *total) -> uint32_t {
-            uint32_t bits[16];
-#pragma unroll
-            for (int w4 = 0; w4 < 4; w4++) {
-                const uint4 v = *(const uint4 *)&bitsOf[16u * k + 4u * (uint32_t)w4];
-                bits[4 * w4] = v.x; bits[4 * w4 + 1] = v.y; bits[4 * w4 + 2] = v.z; bits[4 * w4 + 3] = v.w;
-            }
             uint32_t pos = CU_NONE, seen = 0;
+#pragma unroll 1
+            for (uint32_t w4 = 0; w4 < 4u; w4++) {                  // (a rolled loop of four reads: unrolled, its sixteen words and the hops' state spilled)
+                const uint4 v = *(const uint4 *)&bitsOf[16u * k + 4u * w4];
+                const uint32_t b4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int w = 0; w < 16; w++) {
-                const uint32_t pc = (uint32_t)__builtin_popcount(bits[w]);
-                if (pos == CU_NONE && seen + pc > j) {
-                    uint32_t b = bits[w];
-                    for (uint32_t r = j - seen; r; r--) b &= b - 1u;
-                    pos = (16u * k + (uint32_t)w) * 32u + (uint32_t)__builtin_ctz(b);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t pc = (uint32_t)__builtin_popcount(b4[q]);
+                    if (pos == CU_NONE && seen + pc > j) {
+                        uint32_t b = b4[q];
+                        for (uint32_t r = j - seen; r; r--) b &= b - 1u;
+                        pos = (16u * k + 4u * w4 + (uint32_t)q) * 32u + (uint32_t)__builtin_ctz(b);
+                    }
+                    seen += pc;
                 }
-                seen += pc;
             }
             *total = seen;
             return pos;
@@ -449,11 +448,17 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 if (j == 0 && total > CU_CAND) misc[CM_OVERFLOW] = 1u;
                 if (pos != CU_NONE) {
                     q = CU_STOP;
-                    bool found = false;
+                    uint32_t at = CU_NONE;                        // where the first round has this position
+#pragma unroll 1
+                    for (uint32_t h = 0; h < 2u; h++) {
+                        const uint4 v = *(const uint4 *)&cpos0[k * CU_CAND0 + 8u * h];
+                        const uint32_t w8[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int j0 = 0; j0 < CU_CAND0; j0++)
-                        if (cpos0[k * CU_CAND0 + j0] == pos) { q = cf0[k * CU_CAND0 + j0]; found = true; }
-                    if (!found) misc[CM_OVERFLOW] = 1u;           // (a second-round candidate is a first-round one, or the segment's first byte)
+                        for (int e = 0; e < 8; e++)
+                            if (((w8[e >> 1] >> (16 * (e & 1))) & 0xffffu) == pos) at = k * CU_CAND0 + 8u * h + (uint32_t)e;
+                    }
+                    if (at != CU_NONE) q = cf0[at];
+                    else misc[CM_OVERFLOW] = 1u;                  // (a second-round candidate is a first-round one, or the segment's first byte)
                 }
             }
             cpos[n] = (uint16_t)pos;
