@@ -46,40 +46,36 @@ namespace lz4dev {
 
 #define CU_THREADS 1024
 #define CU_WAVES 16
-#define CU_CHUNK 32            // bytes of compressed stream per lane of the parse
-#define CU_SUPER 512           // bytes per super-chunk (16 chunks)
+#define CU_CHUNK 16            // bytes of compressed stream per lane of the parse (32 with 64 KiB segments: a segment of half the size
+                               // left half the lanes idle in the parse's two per-lane phases, which cost the same per lane)
+#define CU_CHUNK_LOG 4
+#define CU_SUPER 256           // bytes per super-chunk (16 chunks)
+#define CU_SUPER_WORDS (CU_SUPER / 32)   // words of a candidate bit vector per super-chunk
 #define CU_CAND0 16            // first-round candidates per super-chunk (every position a chunk's T[] names)
 #define CU_CAND 4              // candidate entries kept per super-chunk
 #define CU_NODES 384           // list nodes: super-chunks x candidates (<= 84 x 4), the last one is the list's end
 #define CU_LEVELS 7            // pointer doubling: the list has at most one node per super-chunk, 2^7 > 84
-#define CU_CMAX 43008          // compressed bytes of a segment (3.125 x CMAX + tables fit the LDS during the parse)
-#define CU_OUTMAX 65536        // output bytes of a segment
-#define CU_NMAX 8192           // sequences of a segment
-#define CU_GENS (CU_NMAX / CU_THREADS)
+#define CU_CMAX 22528          // compressed bytes of a segment: 1408 chunks (enough for 32 KiB of output down to a ratio of 1.45)
+#define CU_OUTMAX 32768        // output bytes of a segment (a 16-bit source pointer per byte: 64 KiB of LDS)
+#define CU_NMAX 4096           // sequences of a segment
 #define CU_STOP 0xffffu        // T[]: the chain from here meets a sequence that is not plain before it leaves the chunk
 #define CU_NONE 0xffffu
 #define CU_REDO ((int)0x80000001)   // result of a block the form leaves to the lane-parallel decoder
 #define CU_IDLE_LIMIT 2000000u   // polls without progress after which a wave gives the block up (never reached: see there)
 #define CU_TAILMAX 512u         // compressed bytes left to the sequential decoder at the block's end
 #define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
-#ifndef CU_MWAVES
-#define CU_MWAVES 8u            // waves that walk the dependence graph (measured, 160 blocks lzsynth / text, us in this phase: 4 waves 80 / 95,
-                               // 8: 80 / 80, 16: 86 / 77; two groups per wave: 150 / 145 -- a poll costs instructions, not round trips)
-#endif
-#ifndef CU_SLOTS
-#define CU_SLOTS 1              // 64-sequence groups a wave works on at a time
-#endif
-
-// LDS map (bytes).  [0, 70 KiB): the compressed segment during the parse, the output afterwards.  Behind the compressed
-// bytes: T[], two bytes per compressed byte, dead once every chunk has its entry.  [70, 136 KiB): sequence records, written
-// by the chunks' second walk.  [136, 160 KiB): the parse's small tables, then the rank records and the done bits.
+// LDS map (bytes).  [0, 33 KiB): the segment's output (during the parse: the compressed bytes, up to 47 KiB of them with their
+// padding).  [33, 97 KiB): a 16-bit source pointer per output byte (during the parse: part of T[], two bytes per compressed
+// byte behind the compressed bytes, dead once every chunk has its entry).  [97, 129 KiB): sequence records, written by the
+// chunks' second walk.  [136, 160 KiB): the parse's small tables, then the rank records.
 // A SIMD issues one wave-instruction in four cycles and an LDS round trip is ~100 ns, so the phases are written for few
-// instructions and few dependent round trips, and both big tables are laid out for the access a whole wave makes at once
-// -- lane L working on chunk L:
-//   * the compressed bytes are staged with 4 bytes of padding behind every 32 (chunk stride 9 dwords: lanes that read
-//     "their" byte k hit 32 different banks; unpadded, chunk stride 8 dwords, they hit 4);
-//   * T[] is transposed: the entry of byte p lies at (p % 32) * chunks + p / 32, so the lanes' k-th entries are neighbours.
-#define CU_OFF_REC 71680
+// instructions and few dependent round trips, and both big tables of the parse are laid out for the access a whole wave makes
+// at once -- lane L working on chunk L:
+//   * the compressed bytes are staged with 4 bytes of padding behind every 16 (chunk stride 5 dwords: lanes that read
+//     "their" byte k hit 32 different banks; unpadded, chunk stride 4 dwords, they hit 8);
+//   * T[] is transposed: the entry of byte p lies at (p % 16) * chunks + p / 16, so the lanes' k-th entries are neighbours.
+#define CU_OFF_PTR 33792
+#define CU_OFF_REC 99328
 #define CU_OFF_TAB 139264
 #define CU_LDS_BYTES 163840
 // ... tables of the parse
@@ -95,12 +91,11 @@ namespace lz4dev {
 #define CU_TAB_SCAN 21760      // u32[64]     workgroup scans
 #define CU_TAB_J CU_TAB_CBITS
 // ... after the parse
-#define CU_TAB_RANK 0          // uint4[1025]
-#define CU_TAB_DONE 16400      // u32[256]
-enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_COUNT };
+#define CU_TAB_RANK 0          // uint4[513]
+enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_CHANGED, CM_COUNT };
 
 // byte p of the staged segment lives at LDS offset cu_at(p)
-__device__ __forceinline__ uint32_t cu_at(uint32_t p) { return p + ((p >> 5) << 2); }
+__device__ __forceinline__ uint32_t cu_at(uint32_t p) { return p + ((p >> CU_CHUNK_LOG) << 2); }
 // four bytes from byte p on (two aligned dwords + a funnel; the dwords may lie either side of a chunk's padding)
 __device__ __forceinline__ uint32_t cu_u32(const uint8_t *comp, uint32_t p)
 {
@@ -287,7 +282,11 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         }
         const uint8_t *ssrc = src + ipBase;
         uint8_t *sdst = dst + opBase;
-        const uint32_t C = min(remIn, (uint32_t)CU_CMAX);        // bytes staged
+        // bytes staged: what a segment's 32 KiB of output need at the block's ratio so far (the header's for the first segment),
+        // and a quarter more -- the parse's tables cost time per staged byte whether the segment gets to use it or not
+        const uint64_t est = (opBase > 4096) ? ((uint64_t)CU_OUTMAX * (uint64_t)ipBase / (uint64_t)opBase)
+                                            : ((uint64_t)CU_OUTMAX * (uint64_t)srcLen / (uint64_t)cap);
+        const uint32_t C = min(min(remIn, (uint32_t)CU_CMAX), (uint32_t)min(est + est / 4u + 2048u, (uint64_t)CU_CMAX));        // bytes staged
         const uint32_t capSeg = min(remCap, (uint32_t)CU_OUTMAX);
         const uint32_t inLim = C - 32u;                          // a plain sequence ends at or before this
         const uint32_t plim = inLim - 2u;                        // ... so its token lies before this
@@ -296,7 +295,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         const uint32_t NCH = 16u * nSuper;                       // chunks the tables are laid out for
         const uint32_t nNodes = nSuper * CU_CAND;
         uint16_t *Tt = (uint16_t *)(lds + ((cu_at(C + 64u) + 64u + 15u) & ~15u));
-        auto T_at = [&](uint32_t p) -> uint16_t & { return Tt[(p & 31u) * NCH + (p >> 5)]; };
+        auto T_at = [&](uint32_t p) -> uint16_t & { return Tt[(p & (CU_CHUNK - 1u)) * NCH + (p >> CU_CHUNK_LOG)]; };
         uint16_t *entry = (uint16_t *)(tab + CU_TAB_ENTRY);
         uint32_t *cbits = (uint32_t *)(tab + CU_TAB_CBITS);
         uint32_t *cbits1 = (uint32_t *)(tab + CU_TAB_CBITS1);
@@ -338,12 +337,12 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         // group is one LDS round trip.
         for (uint32_t c = tid; c < nChunks; c += CU_THREADS) {
             const uint32_t base = c * CU_CHUNK, cend = base + CU_CHUNK;
-            uint32_t W[9];
+            uint32_t W[CU_CHUNK / 4 + 1];
             {
                 const uint32_t *wp = (const uint32_t *)(comp + cu_at(base));
 #pragma unroll
-                for (int j = 0; j < 8; j++) W[j] = wp[j];
-                W[8] = *(const uint32_t *)(comp + cu_at(base + 32u));
+                for (int j = 0; j < CU_CHUNK / 4; j++) W[j] = wp[j];
+                W[CU_CHUNK / 4] = *(const uint32_t *)(comp + cu_at(base + CU_CHUNK));
             }
             // (the chunk's upper half first, then the lower: the backward pass of the lower half finds the upper half's entries in
             // LDS like everything else it looks up, and sixteen successors are live at a time instead of thirty-two)
@@ -352,7 +351,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 uint32_t S[CU_CHUNK / 2];
 #pragma unroll
                 for (int kk = 0; kk < CU_CHUNK / 2; kk++) {
-                    const int k = 16 * half + kk;
+                    const int k = (CU_CHUNK / 2) * half + kk;
                     const uint32_t p = base + (uint32_t)k;
                     const uint32_t t = (W[k >> 2] >> (8 * (k & 3))) & 0xffu;
                     const uint32_t b1 = (W[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xffu;
@@ -382,7 +381,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                     for (int j = 0; j < 3; j++) {
                         const int kk = g - j;
                         if (kk >= 0) {
-                            const int k = 16 * half + kk;
+                            const int k = (CU_CHUNK / 2) * half + kk;
                             const uint32_t p = base + (uint32_t)k;
                             const uint32_t sv = (S[kk] < cend) ? r[j] : S[kk];
                             Tt[(uint32_t)k * NCH + c] = (uint16_t)sv;
@@ -400,8 +399,8 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         auto nth_cand = [&](const uint32_t *bitsOf, uint32_t k, uint32_t j, uint32_t *total) -> uint32_t {
             uint32_t pos = CU_NONE, seen = 0;
 #pragma unroll 1
-            for (uint32_t w4 = 0; w4 < 4u; w4++) {                  // (a rolled loop of four reads: unrolled, its sixteen words and the hops' state spilled)
-                const uint4 v = *(const uint4 *)&bitsOf[16u * k + 4u * w4];
+            for (uint32_t w4 = 0; w4 < CU_SUPER_WORDS / 4u; w4++) {    // (a rolled loop: unrolled, the words and the hops' state spilled)
+                const uint4 v = *(const uint4 *)&bitsOf[CU_SUPER_WORDS * k + 4u * w4];
                 const uint32_t b4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -409,7 +408,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                     if (pos == CU_NONE && seen + pc > j) {
                         uint32_t b = b4[q];
                         for (uint32_t r = j - seen; r; r--) b &= b - 1u;
-                        pos = (16u * k + 4u * w4 + (uint32_t)q) * 32u + (uint32_t)__builtin_ctz(b);
+                        pos = (CU_SUPER_WORDS * k + 4u * w4 + (uint32_t)q) * 32u + (uint32_t)__builtin_ctz(b);
                     }
                     seen += pc;
                 }
@@ -592,10 +591,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         if (nPar > 0u) {
             uint4 *rk = (uint4 *)(tab + CU_TAB_RANK);
             uint32_t *rkw = (uint32_t *)rk;
-            uint32_t *done = (uint32_t *)(tab + CU_TAB_DONE);
-            rk[tid] = make_uint4(0u, 0u, 0u, 0u);
-            if (tid == 0) rk[CU_THREADS] = make_uint4(0u, 0u, 0u, 0u);
-            if (tid < CU_NMAX / 32) done[tid] = 0u;
+            if (tid <= CU_OUTMAX / 64) rk[tid] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
 
             // ---------------- 3. literals, and what a match takes from in front of the segment (global memory both) ----------------
@@ -650,223 +646,77 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
             stamp();                                              // [11] literals
             // rank records: sequences that start before each group of 64 output positions
             {
-                const uint4 w = rk[tid];
+                uint4 w = make_uint4(0u, 0u, 0u, 0u);
+                if (tid < CU_OUTMAX / 64) w = rk[tid];
                 const uint32_t cnt = (uint32_t)__builtin_popcount(w.x) + (uint32_t)__builtin_popcount(w.y);
                 uint32_t tot;
                 const uint32_t pre = cu_scan_excl(cnt, scanTmp, &tot);
-                rkw[4u * tid + 2u] = pre;
+                if (tid < CU_OUTMAX / 64) rkw[4u * tid + 2u] = pre;
             }
             __syncthreads();
             stamp();                                              // [12] rank records
 
             // ---------------- 4. matches ----------------
-            // index of the sequence that holds output position x
-            auto rank = [&](uint32_t x) -> uint32_t {
-                const uint4 r = rk[x >> 6];
-                const uint32_t m = (2u << (x & 31u)) - 1u;
-                const bool hi = (x & 32u) != 0u;
-                return r.z + (uint32_t)__builtin_popcount(r.x & (hi ? ~0u : m)) + (uint32_t)__builtin_popcount(r.y & (hi ? m : 0u)) - 1u;
-            };
-            // Every sequence's record becomes its match: {destination (LDS index) | length << 17, offset | wait << 16}, wait =
-            // first sequence its source overlaps (13 bits; 0x1fff: none, the source is literals of its own) | how many more
-            // (3 bits; 7: "up to the sequence in front of me").  A match that is complete already (length 0: all of it came
-            // from in front of the segment) sets its done bit here.  (All reads of the old records first, then the writes.)
+            // Every output byte gets a 16-bit SOURCE POINTER: itself when it is in place already (a literal, or a byte a match took
+            // from in front of the segment), else the byte its match copies (cbits/lz4.c:1866-1924: op - offset + k).  Pointer jumping
+            // -- ptr[x] = ptr[ptr[x]], every byte at once, all sixteen waves, in place (every value a pointer ever holds is an ancestor
+            // of its byte, so the order of the updates does not matter) -- halves every chain per round: the dependence graph of a
+            // segment is 80 to 300 matches deep (32 768 for a run of one byte) and is resolved in 8 to 10 rounds (16), whatever it looks
+            // like; then every byte is fetched from the literal its pointer has arrived at.  The first form of this phase walked the
+            // graph match by match through done bits -- eight waves polling, one to three of 64 lanes busy per step: 0.9 us a level,
+            // 91-94 us of a 64 KiB segment's 134-155.
             {
-                uint32_t g0[CU_GENS], g1[CU_GENS];
-#pragma unroll
-                for (int g = 0; g < CU_GENS; g++) {
-                    const uint32_t i = (uint32_t)g * CU_THREADS + tid;
-                    g0[g] = 0u; g1[g] = 0u;
-                    if (i < nPar) {
-                        const uint2 r = rec[i];
-                        const uint32_t outStart = r.x & 0xffffu, lit = r.y & 0xffffu, off = r.y >> 16;
-                        const uint32_t nextStart = rec[i + 1u].x & 0xffffu;
-                        const uint32_t dpos = outStart + lit, ml = nextStart - dpos;
-                        const uint32_t spos = dpos - off;                     // (>= 0: what lay in front of the segment is in place)
-                        const uint32_t srcHi = min(spos + ml, outStart);      // bytes from outStart on are my own
-                        uint32_t code = 0x1fffu;
-                        if (ml != 0u && srcHi > spos) {
-                            const uint32_t jlo = rank(spos), span = rank(srcHi - 1u) - jlo;
-                            code = jlo | (min(span, 7u) << 13);
-                        }
-                        g0[g] = (A + dpos) | (ml << 17);
-                        g1[g] = off | (code << 16);
-                    }
+                uint32_t *ptr32 = (uint32_t *)(lds + CU_OFF_PTR);            // two pointers a word: bytes 2k and 2k + 1
+                const uint16_t *ptr16 = (const uint16_t *)(lds + CU_OFF_PTR);
+                const uint32_t nPairs = (tailOp + 1u) / 2u;
+                for (uint32_t k = tid; k < nPairs; k += CU_THREADS) {
+                    const uint32_t x0 = 2u * k, x1 = x0 + 1u;
+                    // the sequences that hold x0 and x1: one rank record serves both (x0 is even)
+                    const uint4 rr = rk[x0 >> 6];
+                    const bool hi = (x0 & 32u) != 0u;
+                    const uint32_t m0 = (2u << (x0 & 31u)) - 1u, m1 = (2u << (x1 & 31u)) - 1u;
+                    const uint32_t i0 = rr.z + (uint32_t)__builtin_popcount(rr.x & (hi ? ~0u : m0)) + (uint32_t)__builtin_popcount(rr.y & (hi ? m0 : 0u)) - 1u;
+                    const uint32_t i1 = rr.z + (uint32_t)__builtin_popcount(rr.x & (hi ? ~0u : m1)) + (uint32_t)__builtin_popcount(rr.y & (hi ? m1 : 0u)) - 1u;
+                    const uint2 r0 = rec[i0];
+                    uint2 r1 = r0;
+                    if (i1 != i0) r1 = rec[i1];
+                    // (a record: first output byte | ..., literals -- and what came from in front of the segment -- | offset << 16)
+                    const uint32_t d0 = (r0.x & 0xffffu) + (r0.y & 0xffffu), d1 = (r1.x & 0xffffu) + (r1.y & 0xffffu);
+                    const uint32_t p0 = (x0 < d0) ? x0 : x0 - (r0.y >> 16);
+                    const uint32_t p1 = (x1 < d1 || x1 >= tailOp) ? x1 : x1 - (r1.y >> 16);
+                    ptr32[k] = p0 | (p1 << 16);
                 }
                 __syncthreads();
-#pragma unroll
-                for (int g = 0; g < CU_GENS; g++) {
-                    const uint32_t i = (uint32_t)g * CU_THREADS + tid;
-                    if (i < nPar) {
-                        rec[i] = make_uint2(g0[g], g1[g]);
-                        if ((g0[g] >> 17) == 0u) atomicOr(&done[i >> 5], 1u << (i & 31u));
-                    }
+                // rounds: a pair of pointers that does not move any more points at bytes that are in place, and is left alone
+                uint32_t live = 0u;
+                {
+                    uint32_t m = 0u;
+                    for (uint32_t k = tid; k < nPairs; k += CU_THREADS) live |= 1u << m++;
                 }
-                __syncthreads();
-            }
-            // The dependence graph is walked by CU_MWAVES waves; the others wait at the barrier.  A poll that finds nothing costs
-            // its wave's SIMD the same issue slots as one that does (a SIMD issues one wave-instruction in four cycles): with
-            // sixteen waves polling eight groups each, the few that had a copy to make got a quarter of their SIMD (measured:
-            // 1.5 us per level of the graph).  Wave w owns the 64-sequence groups w, w + CU_MWAVES, ... and works on CU_SLOTS of
-            // them at a time, in order (the graph is walked from the segment's start to its end; what becomes ready far ahead of
-            // that front loses nothing by waiting for a slot).  LDS operations of a wave execute in order and the LDS serves the
-            // CU's waves in arrival order, so a done bit set behind a copy's stores is seen behind them: no waits, only compiler
-            // fences.
-            if ((uint32_t)wave < CU_MWAVES) {
-                const uint32_t nGrp = (nPar + LZ4_WAVE - 1u) / LZ4_WAVE;      // 64-sequence groups in all; done[] words 2 grp, 2 grp + 1
-                uint32_t nextGrp = (uint32_t)wave;
-                uint32_t sg[CU_SLOTS], wlo[CU_SLOTS], whi[CU_SLOTS], f0[CU_SLOTS], f1[CU_SLOTS];
-                bool pd[CU_SLOTS];
-                auto load = [&](int sl) {
-                    sg[sl] = 0xffffffffu; pd[sl] = false; wlo[sl] = 1u; whi[sl] = 0u; f0[sl] = 0u; f1[sl] = 1u;
-                    while (nextGrp < nGrp && sg[sl] == 0xffffffffu) {
-                        const uint32_t i = nextGrp * LZ4_WAVE + (uint32_t)lane;
-                        bool mine = false;
-                        if (i < nPar) {
-                            const uint2 r = rec[i];
-                            f0[sl] = r.x; f1[sl] = r.y & 0xffffu;
-                            const uint32_t code = r.y >> 16, jlo = code & 0x1fffu, span = code >> 13;
-                            wlo[sl] = 1u; whi[sl] = 0u;
-                            if (jlo != 0x1fffu) { wlo[sl] = jlo; whi[sl] = (span == 7u) ? i - 1u : jlo + span; }
-                            mine = (r.x >> 17) != 0u;
-                        }
-                        pd[sl] = mine;
-                        if (__ballot(mine)) sg[sl] = nextGrp;           // (a group with nothing left to copy is skipped)
-                        nextGrp += CU_MWAVES;
+                for (int round = 0; round < 17; round++) {
+                    bool changed = false;
+                    uint32_t m = 0u;
+                    for (uint32_t k = tid; k < nPairs; k += CU_THREADS, m++) {
+                        if (!((live >> m) & 1u)) continue;
+                        const uint32_t v = ptr32[k];
+                        const uint32_t q0 = ptr16[v & 0xffffu], q1 = ptr16[v >> 16];
+                        const uint32_t nv = q0 | (q1 << 16);
+                        if (nv != v) { ptr32[k] = nv; changed = true; }
+                        else live &= ~(1u << m);
                     }
-                    if (sg[sl] == 0xffffffffu) pd[sl] = false;
-                };
-#pragma unroll
-                for (int sl = 0; sl < CU_SLOTS; sl++) load(sl);
-                uint32_t idle = 0, nIter = 0, nProg = 0;
-                for (;;) {
-                    bool any = false;
-#pragma unroll
-                    for (int sl = 0; sl < CU_SLOTS; sl++) any = any || sg[sl] != 0xffffffffu;
-                    if (!any) break;
-                    nIter++;
-                    // ---- poll: the slots' done words, and -- behind them, in the same batch -- the first 32 bytes of every pending
-                    // match's source.  LDS reads of a wave execute in order: if the done word shows the sources complete, the bytes
-                    // read behind it are final; if not, they are dropped.  One round trip per poll instead of two. ----
-                    uint32_t dw[CU_SLOTS];
-                    uint32_t d[CU_SLOTS], sA[CU_SLOTS], off[CU_SLOTS], ml[CU_SLOTS];
-                    bool g16[CU_SLOTS], g8[CU_SLOTS], g4[CU_SLOTS];
-                    par_v4 v0[CU_SLOTS], v1[CU_SLOTS];
-#pragma unroll
-                    for (int sl = 0; sl < CU_SLOTS; sl++) {
-                        dw[sl] = 0u;
-                        if (pd[sl] && wlo[sl] <= whi[sl]) dw[sl] = __atomic_load_n(&done[wlo[sl] >> 5], __ATOMIC_RELAXED);
-                        d[sl] = f0[sl] & 0x1ffffu; ml[sl] = pd[sl] ? f0[sl] >> 17 : 0u; off[sl] = pd[sl] ? f1[sl] : 1u;
-                        sA[sl] = d[sl] - off[sl];
-                        // the classes are decode_par.hpp's (step 7): chunks that never read their own writes; one 16-byte read serves
-                        // every class (the bytes past a short match are read and dropped, the short classes' second chunk is cut out
-                        // of it in registers)
-                        const bool w8 = ml[sl] >= 8u && off[sl] >= 8u;
-                        const bool grp = w8 && (off[sl] >= 32u || off[sl] >= ml[sl]);
-                        g16[sl] = grp && ml[sl] >= 16u;
-                        g8[sl] = grp && ml[sl] < 16u;
-                        g4[sl] = ml[sl] >= 4u && ml[sl] < 8u && off[sl] >= ml[sl];
-                        v0[sl] = (par_v4){0u, 0u, 0u, 0u}; v1[sl] = v0[sl];
-                        if (g16[sl] || g8[sl] || g4[sl]) v0[sl] = *(const par_v4u *)&out[sA[sl]];
-                        if (g16[sl] && ml[sl] > 16u) v1[sl] = *(const par_v4u *)&out[sA[sl] + min(16u, ml[sl] - 16u)];
-                    }
-                    // ---- which of my sequences are ready ----
-                    bool ready[CU_SLOTS];
-#pragma unroll
-                    for (int sl = 0; sl < CU_SLOTS; sl++) {
-                        ready[sl] = false;
-                        if (pd[sl]) {
-                            const uint32_t lo = wlo[sl], hi = whi[sl];
-                            if (lo > hi) ready[sl] = true;
-                            else {
-                                const bool last = (hi >> 5) == (lo >> 5);
-                                const uint32_t hiB = last ? (hi & 31u) : 31u;
-                                const uint32_t m = ((2u << hiB) - 1u) & ~((1u << (lo & 31u)) - 1u);
-                                const uint32_t miss = ~dw[sl] & m;
-                                if (miss) wlo[sl] = (lo & ~31u) + (uint32_t)__builtin_ctz(miss);
-                                else if (last) ready[sl] = true;
-                                else wlo[sl] = (lo | 31u) + 1u;
-                            }
-                        }
-                    }
-                    uint64_t rm[CU_SLOTS];
-                    bool progress = false;
-#pragma unroll
-                    for (int sl = 0; sl < CU_SLOTS; sl++) { rm[sl] = __ballot(ready[sl]); progress = progress || rm[sl] != 0ull; }
-                    if (progress) {
-                        bool slow[CU_SLOTS];
-#pragma unroll
-                        for (int sl = 0; sl < CU_SLOTS; sl++) {
-                            g16[sl] = g16[sl] && ready[sl]; g8[sl] = g8[sl] && ready[sl]; g4[sl] = g4[sl] && ready[sl];
-                            slow[sl] = ready[sl] && !(g16[sl] || g8[sl] || g4[sl]);
-                            if (g16[sl]) {
-                                *(par_v4u *)&out[d[sl]] = v0[sl];
-                                if (ml[sl] > 16u) *(par_v4u *)&out[d[sl] + min(16u, ml[sl] - 16u)] = v1[sl];
-                            }
-                            const uint32_t sh = ml[sl] - 8u;                                  // g8: 0..7
-                            const bool up = (sh & 4u) != 0u;
-                            const uint32_t lo = up ? v0[sl].y : v0[sl].x, mid = up ? v0[sl].z : v0[sl].y, hi = up ? v0[sl].w : v0[sl].z;
-                            if (g8[sl]) {
-                                *(par_u64u *)&out[d[sl]] = (uint64_t)v0[sl].x | ((uint64_t)v0[sl].y << 32);
-                                *(par_u64u *)&out[d[sl] + sh] = (uint64_t)__builtin_amdgcn_alignbyte(mid, lo, sh & 3u) |
-                                                                ((uint64_t)__builtin_amdgcn_alignbyte(hi, mid, sh & 3u) << 32);
-                            }
-                            if (g4[sl]) {
-                                *(par_u32u *)&out[d[sl]] = v0[sl].x;
-                                *(par_u32u *)&out[d[sl] + ml[sl] - 4u] = __builtin_amdgcn_alignbyte(v0[sl].y, v0[sl].x, (ml[sl] - 4u) & 3u);
-                            }
-                        }
-                        // matches longer than 32 bytes: 32 more per step (both reads of a step before its writes)
-                        for (uint32_t base = 32u;; base += 32u) {
-                            bool more = false;
-#pragma unroll
-                            for (int sl = 0; sl < CU_SLOTS; sl++) more = more || (g16[sl] && base < ml[sl]);
-                            if (!__ballot(more)) break;
-                            par_v4 a[CU_SLOTS], b[CU_SLOTS];
-                            uint32_t o0[CU_SLOTS], o1[CU_SLOTS];
-#pragma unroll
-                            for (int sl = 0; sl < CU_SLOTS; sl++) {
-                                const bool on = g16[sl] && base < ml[sl];
-                                o0[sl] = min(base, ml[sl] - 16u); o1[sl] = min(base + 16u, ml[sl] - 16u);
-                                a[sl] = (par_v4){0u, 0u, 0u, 0u}; b[sl] = a[sl];
-                                if (on) { a[sl] = *(const par_v4u *)&out[sA[sl] + o0[sl]]; b[sl] = *(const par_v4u *)&out[sA[sl] + o1[sl]]; }
-                            }
-#pragma unroll
-                            for (int sl = 0; sl < CU_SLOTS; sl++)
-                                if (g16[sl] && base < ml[sl]) { *(par_v4u *)&out[d[sl] + o0[sl]] = a[sl]; *(par_v4u *)&out[d[sl] + o1[sl]] = b[sl]; }
-                        }
-                        // the rest (matches that overlap their own output, what is left of a match shorter than four bytes) one
-                        // after the other by the whole wave
-#pragma unroll
-                        for (int sl = 0; sl < CU_SLOTS; sl++)
-                            for (uint64_t sm = __ballot(slow[sl]); sm; sm &= sm - 1ull) {
-                                const int k = (int)__builtin_ctzll(sm);
-                                cu_wave_copy(out, (uint32_t)__builtin_amdgcn_readlane((int)d[sl], k), (uint32_t)__builtin_amdgcn_readlane((int)sA[sl], k),
-                                             (uint32_t)__builtin_amdgcn_readlane((int)off[sl], k), (uint32_t)__builtin_amdgcn_readlane((int)ml[sl], k));
-                            }
-                        wave_fence();
-                        if (lane == 0) {
-#pragma unroll
-                            for (int sl = 0; sl < CU_SLOTS; sl++) {
-                                if ((uint32_t)rm[sl]) atomicOr(&done[2u * sg[sl]], (uint32_t)rm[sl]);
-                                if ((uint32_t)(rm[sl] >> 32)) atomicOr(&done[2u * sg[sl] + 1u], (uint32_t)(rm[sl] >> 32));
-                            }
-                        }
-#pragma unroll
-                        for (int sl = 0; sl < CU_SLOTS; sl++) {
-                            if (ready[sl]) pd[sl] = false;
-                            if (sg[sl] != 0xffffffffu && !__ballot(pd[sl])) load(sl);
-                        }
-                    }
-                    if (!progress) {
-                        // Every wait is for a sequence with a smaller index, and the group that holds it is in a slot or done
-                        // (groups enter slots in order): some wave always makes progress; the limit only guarantees that a launch
-                        // ends whatever state its tables are in (the block is then decoded again)
-                        if (++idle > CU_IDLE_LIMIT) { if (lane == 0) __atomic_store_n(&misc[CM_ABORT], 1u, __ATOMIC_RELAXED); }
-                        if (__atomic_load_n(&misc[CM_ABORT], __ATOMIC_RELAXED)) break;
-                    } else { idle = 0; nProg++; }
+                    // (one word says whether any pointer moved: round r stores r + 1, and the word only grows, so a thread that
+                    // reads it late -- behind a store of round r + 1 -- decides as the others did)
+                    if (changed) __atomic_store_n(&misc[CM_CHANGED], (uint32_t)round + 1u, __ATOMIC_RELAXED);
+                    __syncthreads();
+                    if (__atomic_load_n(&misc[CM_CHANGED], __ATOMIC_RELAXED) < (uint32_t)round + 1u) break;
                 }
-                if (dbg && tid == 0 && seg == 0) dbg[3] = (nIter << 16) | (nProg & 0xffffu);
+                // every byte from the byte its pointer has arrived at (a byte in place points at itself)
+                for (uint32_t k = tid; k < nPairs; k += CU_THREADS) {
+                    const uint32_t v = ptr32[k];
+                    const uint32_t b0 = out[A + (v & 0xffffu)], b1 = out[A + (v >> 16)];
+                    out[A + 2u * k] = (uint8_t)b0;
+                    if (2u * k + 1u < tailOp) out[A + 2u * k + 1u] = (uint8_t)b1;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
