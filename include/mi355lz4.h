@@ -119,7 +119,7 @@ int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
 int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
 /* Decoder variant: 0 = chosen per call (default), 1 = sequence-at-a-time kernel, 2 = lane-parallel kernel (one wavefront
  * per block: what fills the GPU when a call brings thousands of blocks), 4 = one workgroup per block (sixteen wavefronts
- * share a block's output in LDS: a block's latency is 1.5-2 x shorter, a 4 MiB block's 2 x; independent blocks only, a
+ * share a block's output in LDS, 32 KiB at a time: a block's latency is 1.5-2 x shorter; independent blocks only, a
  * linked call takes variant 2).  Variant 0 takes variant 4 for calls of up to 256 blocks (MI355LZ4_CU_BLOCKS in the
  * environment overrides the count; 0 = never) and variant 2 otherwise.
  * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */

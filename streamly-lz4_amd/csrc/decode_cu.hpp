@@ -5,27 +5,29 @@
 // wavefront, which is what fills the chip when a call brings tens of thousands of blocks; but a wave on its own issues one
 // instruction in four to eight cycles and decodes 0.2-0.3 GB/s, so a call of 160 blocks -- the reference's own benchmark
 // protocol, benchmark/Main.hs:80-84 -- took one block's latency on a GPU that was 97 % idle, and a 4 MiB block
-// (Config.hs:109-116) took 24 ms.  Here a block is decoded in SEGMENTS of at most 42 KiB of compressed bytes and 64 KiB of
+// (Config.hs:109-116) took 6 ms.  Here a block is decoded in SEGMENTS of at most 22 KiB of compressed bytes and 32 KiB of
 // output; a segment's output lives in LDS and sixteen waves work on it:
 //
 //   1. stage      the segment's compressed bytes into LDS.
 //   2. parse      EXACT and parallel.  succ(p) = where the next token is if a token starts at byte p
-//                 (cbits/lz4.c:1801-1854).  Every lane takes a 32-byte chunk and computes, for every byte p of it,
+//                 (cbits/lz4.c:1801-1854).  Every lane takes a 16-byte chunk and computes, for every byte p of it,
 //                 T[p] = the first position at or behind the chunk's end that the chain from p reaches (backwards, so
-//                 T[p] = T[succ(p)] inside the chunk).  A chain can only ENTER a 512-byte super-chunk at a position some
+//                 T[p] = T[succ(p)] inside the chunk).  A chain can only ENTER a 256-byte super-chunk at a position some
 //                 T[p] names (a bit vector; 7 to 9 positions per super-chunk).  Each of those hops T[] through its
 //                 super-chunk (<= 16 hops); where they LEAVE it are the candidates (one or two per super-chunk: chains
-//                 that ran for 512 bytes have met).  The candidates form a linked list of <= 384 nodes which one wave
+//                 that ran for a while have met).  The candidates form a linked list of <= 384 nodes which one wave
 //                 ranks by pointer doubling; the nodes reachable from the segment's first token are the true entries.
 //                 They hop once more to give every chunk its entry, every chunk's lane walks its few sequences, a scan
 //                 gives each sequence its index and output position.  Nothing is guessed.
 //   3. literals   every sequence's literals go from the compressed bytes to the output in LDS, and so does what a match
 //                 takes from in front of the segment (earlier segments' output or the dictionary, final in global
 //                 memory): no dependences.
-//   4. matches    a match is ready when the sequences its source overlaps are complete.  Sequence starts are bits of a
-//                 bit vector over the output (rank query = sequence index of a byte, as in decode_par.hpp step 5), every
-//                 sequence has a done bit; eight waves walk the dependence graph (depth 80-300 for 2400-6000 sequences),
-//                 each polling the done bits its 64 current sequences wait for: no barrier.
+//   4. matches    BYTE-GRANULAR POINTER JUMPING.  Every output byte gets a 16-bit source pointer: itself if it is in place
+//                 (step 3), else the byte its match copies (op - offset + k, cbits/lz4.c:1866-1924).  ptr[x] = ptr[ptr[x]]
+//                 for every byte at once, in place, halves every chain per round: the dependence graph of a segment -- 80
+//                 to 300 matches deep, 32 768 for a run of one byte -- is resolved in 8 to 10 rounds (16) with every lane
+//                 of sixteen waves busy, whatever it looks like; then every byte is fetched from the byte its pointer
+//                 arrived at.  (The first form walked the graph match by match through done bits: 0.9 us per level.)
 //   5. flush      LDS -> global memory with aligned 16-byte stores.
 //   6. next       the first sequence that is not plain ends the segment.  If it is the output or table limit that ended it,
 //                 the next segment starts there; a sequence the parse does not take (a length with more than two extension bytes, an offset
