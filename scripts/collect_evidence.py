@@ -3,7 +3,7 @@
 profiles/rNN_PROVENANCE.json (commit, files).    python scripts/collect_evidence.py [round]"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 E = os.path.join(ROOT, "gpurun_out", "evidence")
 P = os.path.join(ROOT, "profiles")
 commit = open(os.path.join(E, "commit.txt")).read().strip()
@@ -18,7 +18,10 @@ names = {"bench_roundtrip.json": "bench_roundtrip.json", "bench_random256k.json"
          "linked_async_cost.txt": "linked_async_cost.txt", "linked_single_stream_kernel_stats.csv": "linked_single_stream_kernel_stats.csv", "bench_one_stream_rehearsal.jsonl": "bench_one_stream_rehearsal.jsonl", "realtext_ratio.txt": "realtext_ratio.txt", "size_vs_reference.txt": "size_vs_reference.txt",
          "host_api_rate.jsonl": "host_api_rate.jsonl", "valu_issue_rate.txt": "valu_issue_rate.txt",
          "bench_n2_selflaunch_rehearsal.json": "bench_n2_selflaunch_rehearsal.json", "linked_streams_rate.jsonl": "linked_streams_rate.jsonl", "kernel_resources.txt": "kernel_resources.txt",
-         "bench_roundtrip_8GiB.json": "bench_roundtrip_8GiB.json", "linked_runin_decode.txt": "linked_runin_decode.txt"}
+         "bench_roundtrip_8GiB.json": "bench_roundtrip_8GiB.json", "linked_runin_decode.txt": "linked_runin_decode.txt",
+         "cu_decode_small_calls.jsonl": "cu_decode_small_calls.jsonl", "cu_decode_kernel_stats.csv": "cu_decode_kernel_stats.csv",
+         "cu_decode_lzsynth_pmc_instmix.txt": "cu_decode_lzsynth_pmc_instmix.txt", "cu_decode_text_pmc_instmix.txt": "cu_decode_text_pmc_instmix.txt",
+         "decode_own_vs_reference_written.txt": "decode_own_vs_reference_written.txt", "multi_device_rehearsal.jsonl": "multi_device_rehearsal.jsonl"}
 files = []
 for src, dst in names.items():
     p = os.path.join(E, src)

@@ -41,6 +41,16 @@ python3 scripts/host_api_rate.py > "$E/host_api_rate.jsonl" 2>/dev/null
 rm -f gpurun_out/linked_rate.json; python3 -m pytest tests/test_linked_rate_gpu.py -q -m gpu > "$E/linked_rate_test.log" 2>&1
 rm -f gpurun_out/linked_rate.json.prev; cp gpurun_out/linked_rate.json "$E/linked_streams_rate.jsonl" 2>/dev/null
 scripts/kernel_resources.sh > "$E/kernel_resources.txt" 2>&1
+# round 6: calls that do not fill the GPU (one workgroup per block, csrc/decode_cu.hpp): call times and the first segment's phases,
+# the kernel's rocprofv3 stats and counters, the engine's against the reference's stream in calls of one size, the multi-device handle
+{ python3 scripts/cu_decode_check.py time 2>/dev/null | grep '^{'
+  python3 scripts/cu_decode_check.py time blocks=16 bl=262144 2>/dev/null | grep '^{'
+  python3 scripts/cu_decode_check.py time blocks=256 bl=1048576 2>/dev/null | grep '^{'
+  python3 scripts/cu_decode_check.py time blocks=3 bl=4194304 2>/dev/null | grep '^{'; } > "$E/cu_decode_small_calls.jsonl"
+( cd /tmp && export TMPDIR=/tmp && rm -rf "$E/cu_prof" && rocprofv3 --kernel-trace --stats --output-format csv -d "$E/cu_prof" -- python3 "$R/scripts/prof_cu.py" lzsynth 160 30 > "$E/cu_prof.log" 2>&1; cp "$E"/cu_prof/*/*kernel_stats.csv "$E/cu_decode_kernel_stats.csv" 2>/dev/null )
+for k in lzsynth text; do bash scripts/pmc_cu.sh $k > "$E/cu_decode_${k}_pmc_instmix.txt" 2>&1; done
+python3 scripts/par_stats_ref.py lzsynth 16384 2>/dev/null | grep -v amdgpu > "$E/decode_own_vs_reference_written.txt"
+python3 scripts/multi_device_rate.py 256 2>/dev/null | grep '^{' > "$E/multi_device_rehearsal.jsonl"
 # issue rate of integer vector instructions (section 0 of DESIGN.md prices the decoder with these)
 [ -x scripts/micro/valu_rate.bin ] && scripts/micro/valu_rate.bin > "$E/valu_issue_rate.txt" 2>&1
 # `python3 bench.py --gpus 2` on its own (the script starts its ranks as a child process), rehearsed on this one GPU over gloo

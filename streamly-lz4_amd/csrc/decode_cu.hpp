@@ -160,6 +160,22 @@ __device__ __forceinline__ uint32_t cu_scan_excl(uint32_t v, uint32_t *tmp, uint
     return base + incl - v;
 }
 
+// two such sums at once (one pair of barriers); tmp: 32 words of LDS
+__device__ __forceinline__ void cu_scan_excl2(uint32_t va, uint32_t vb, uint32_t *tmp, uint32_t *pa, uint32_t *pb, uint32_t *ta, uint32_t *tb)
+{
+    const int lane = lane_id(), wave = uni((int)(threadIdx.x >> 6));
+    const uint32_t ia = (uint32_t)par_scan_incl((int)va), ib = (uint32_t)par_scan_incl((int)vb);
+    if (lane == LZ4_WAVE - 1) { tmp[wave] = ia; tmp[16 + wave] = ib; }
+    __syncthreads();
+    uint32_t wa = (lane < CU_WAVES) ? tmp[lane] : 0u, wb = (lane < CU_WAVES) ? tmp[16 + lane] : 0u;
+    const uint32_t sa = (uint32_t)par_scan_incl((int)wa), sb = (uint32_t)par_scan_incl((int)wb);
+    *pa = (uint32_t)__builtin_amdgcn_readlane((int)(sa - wa), wave) + ia - va;
+    *pb = (uint32_t)__builtin_amdgcn_readlane((int)(sb - wb), wave) + ib - vb;
+    *ta = (uint32_t)__builtin_amdgcn_readlane((int)sa, CU_WAVES - 1);
+    *tb = (uint32_t)__builtin_amdgcn_readlane((int)sb, CU_WAVES - 1);
+    __syncthreads();
+}
+
 // n bytes (n >= 1) from global memory to LDS by one lane, 16 at a time (the last piece re-anchored at the end)
 __device__ __forceinline__ void cu_lane_fetch(uint8_t *out, uint32_t dA, const LZ4_GLOBAL uint8_t *g, uint32_t n)
 {
@@ -543,9 +559,8 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 if (a1) { if (s1.nxt == CU_STOP) { a1 = false; n2[1]++; } else { n2[1]++; len2[1] += s1.lit + s1.ml; q1 = s1.nxt; a1 = q1 < cend1; } }
             }
         }
-        uint32_t totN, totLen;
-        const uint32_t seqBase = cu_scan_excl(n2[0] + n2[1], scanTmp, &totN);
-        const uint32_t opScan = cu_scan_excl(len2[0] + len2[1], scanTmp + 32, &totLen);
+        uint32_t totN, totLen, seqBase, opScan;
+        cu_scan_excl2(n2[0] + n2[1], len2[0] + len2[1], scanTmp, &seqBase, &opScan, &totN, &totLen);
         uint32_t myStop = 0xffffffffu, myStopIp = 0, myStopOp = 0, myStopKind = 0;
         {
             uint32_t q0 = e0, q1 = e1;
