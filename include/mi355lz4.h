@@ -119,9 +119,10 @@ int mi355lz4_set_linked_async(mi355lz4_ctx *ctx, int maxDecodedBlockSize);
 int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
 /* Decoder variant: 0 = chosen per call (default), 1 = sequence-at-a-time kernel, 2 = lane-parallel kernel (one wavefront
  * per block: what fills the GPU when a call brings thousands of blocks), 4 = one workgroup per block (sixteen wavefronts
- * share a block's output in LDS, 32 KiB at a time: a block's latency is 1.5-2 x shorter; independent blocks only, a
- * linked call takes variant 2).  Variant 0 takes variant 4 for calls of up to 256 blocks (MI355LZ4_CU_BLOCKS in the
- * environment overrides the count; 0 = never) and variant 2 otherwise.
+ * share a block's output in LDS, 32 KiB at a time: a block's latency is 1.5-2 x shorter; in a linked call it is the
+ * first, standalone pass -- blocks that need their dictionary go through the second pass as ever).  Variant 0 takes
+ * variant 4 for calls of up to 256 blocks (MI355LZ4_CU_BLOCKS in the environment overrides the count; 0 = never) and
+ * variant 2 otherwise.
  * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
 /* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block

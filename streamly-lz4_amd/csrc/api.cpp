@@ -174,6 +174,8 @@ struct mi355lz4_ctx {
     bool runinLong = false;                // a call was given up with the default run-in (chains of pieces to redo): the long one from here on
     int runinLongOk = 0;                   // ... calls in a row that finished with it (after RUNIN_LONG_PROBE the default is tried again)
     int runinSkip = 0;                     // ... and given up with the long one too: this many linked decodes go straight to the pointer pass
+    int linkedPath = -1;                   // diagnostics: how the last linked call was finished (mi355lz4_debug_runin_state)
+    int runinShareE6 = -1;                 // diagnostics: the dictionary share the last linked call sampled, in millionths (-1: none)
     int segMode = -1;                      // small-batch segments per block: -1 auto, 0 off, k forced (mi355lz4_set_segments)
     hipEvent_t linkEvent = nullptr;        // end of the last linked decode's use of linkBuf / tolPool / tolMeta / ptrBuf
     hipStream_t linkStream = nullptr;      // ... and the stream it ran on
@@ -421,12 +423,15 @@ extern "C" int mi355lz4_debug_stats(mi355lz4_ctx *c, int enable, unsigned long l
     return MI355LZ4_OK;
 }
 
-// Diagnostic hook (not part of the public header): the run-in decode's adaptive state {runinLong, runinLongOk, runinSkip}.
-// get (may be null) receives it; set (may be null) replaces it.  Lets a test drive default -> long -> skip -> probe.
+// Diagnostic hook (not part of the public header): the run-in decode's adaptive state {runinLong, runinLongOk, runinSkip} and, in
+// get[3], the dictionary share the last linked call sampled (millionths; -1: none) and, in get[4], how the last linked call was
+// finished: 0 no block needed its dictionary, 1 short runs walked, 2 run-in decode, 3 long run-in decode, 4 run-in decode given up
+// and the lists/pointer passes, 5 the lists/pointer passes (or the walk) at once.  get (may be null, 5 ints) receives it; set (may
+// be null, 3 ints) replaces the state.  Lets a test drive default -> long -> skip -> probe.
 extern "C" int mi355lz4_debug_runin_state(mi355lz4_ctx *c, int *get, const int *set)
 {
     if (!c) return fail(MI355LZ4_E_ARG, "null ctx");
-    if (get) { get[0] = c->runinLong ? 1 : 0; get[1] = c->runinLongOk; get[2] = c->runinSkip; }
+    if (get) { get[0] = c->runinLong ? 1 : 0; get[1] = c->runinLongOk; get[2] = c->runinSkip; get[3] = c->runinShareE6; get[4] = c->linkedPath; }
     if (set) { c->runinLong = set[0] != 0; c->runinLongOk = set[1]; c->runinSkip = set[2]; }
     return MI355LZ4_OK;
 }
@@ -659,6 +664,8 @@ static int cu_auto_blocks()
 #define RUNIN_LONG_64K 17      // the long run-in (blocks of 64 KiB): taken after the default one gave a call up for what the data is like
 #define RUNIN_LONG_PROBE 32    // calls in a row finished with the long run-in before the default is tried again
 #define RUNIN_BACKOFF 16       // linked calls that skip the run-in decode after the long one gave a call up as well
+#define RUNIN_SHARE_LONG 0.306  // sampled share of bytes taken directly from the block before (k_dict_share) from which the long run-in is taken ...
+#define RUNIN_SHARE_NEVER 0.60  // ... and from which the stream is taken to never forget its dictionary (pointer pass)
 static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framedLen, const uint64_t *blockOff,
                          int nBlocks, int headerKind, int fixedUncomp, int linked, uint8_t *out,
                          const uint64_t *outOff, const int32_t *outCap, int32_t *result, const uint8_t *dict0,
@@ -691,7 +698,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     if (linked) {
         link_scratch_acquire(c);
         // the standalone pass counts the blocks that need their dictionary: {count, first, last, -, largest capacity}
-        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 32))) return r;
+        if ((r = dev_reserve(c->linkBuf, 64 + ptr_ctl_bytes() + 4 * nFlags)) || (r = pin_reserve(c->pinStat, 64))) return r;
         a.linkStat = (uint32_t *)c->linkBuf.p;
         HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
         HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
@@ -706,10 +713,12 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         launch_decode_tok(a, c->stream);
     }
 #endif
-    else if (!linked && !c->stats && (c->decoder == 4 || (c->decoder == 0 && nBlocks <= cu_auto_blocks())))
+    else if (!c->stats && (c->decoder == 4 || (c->decoder == 0 && nBlocks <= cu_auto_blocks())))
         // Calls that do not fill the GPU -- one workgroup per block instead of one wavefront (decode_cu.hpp).  A CU takes about
-        // 0.16 ms per 64 KiB of a block, a wavefront 0.2-0.3 ms, but 19 wavefronts share a CU: with more blocks than CUs the
-        // wavefronts win.  (Variant 4 forces it for any number of blocks: the tests.)
+        // 0.12 ms per 64 KiB of a block, a wavefront 0.2-0.3 ms, but 19 wavefronts share a CU: with more blocks than CUs the
+        // wavefronts win.  (Variant 4 forces it for any number of blocks: the tests.)  A linked call's first pass is this
+        // same standalone decode (decompressChunks always asks for linked = 1, and what this engine's compressor writes are
+        // independent blocks): a block that needs its dictionary fails here as it does there -- 50 us later -- and is counted.
         launch_decode_cu(a, c->stream);
     else
         launch_decode_par(a, c->stats, c->stream);
@@ -733,6 +742,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         HIP_TRY(hipMemcpyAsync(stat, a.linkStat, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    c->runinShareE6 = -1; c->linkedPath = 0;
     if (stat[0] == 0) { link_scratch_release(c); return check_launch("decode launch"); }
     int first = (int)stat[1], last = (int)stat[2];
     if (first < 0 || last >= nBlocks || first > last) {
@@ -758,6 +768,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             }
             a.segFirst = first; a.segEnd = last + 1;
             launch_linked_runs(a, c->stream);
+            c->linkedPath = 1;
             link_scratch_release(c);
             return check_launch("decode launch");
         }
@@ -782,7 +793,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         // (the state decays with EVERY linked call that gets here, whatever path it then takes: an engine whose later streams are
         // shorter than the long run-in's threshold would otherwise never try the default again)
         if (!envRun && c->runinLong && ++c->runinLongOk >= RUNIN_LONG_PROBE) { c->runinLong = false; c->runinLongOk = 0; }
-        const bool longRun = c->runinLong && !envRun;
+        bool longRun = c->runinLong && !envRun;
         // (a range begun with mi355lz4_decompress_linked_begin that has no seam to wait for -- the stream's first range --
         // is finished here like a plain call: _end and _end_last then find nothing left to do)
         // (a handful of huge blocks has the bytes but not the pieces: at least 64 dependent blocks; and a piece's ring is two
@@ -792,6 +803,31 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
                                 : (plain && span0 >= 64 && 2u * stride <= ((uint64_t)1 << 31) &&
                                    (uint64_t)span0 * per64 >= (longRun ? 2 * RUNIN_MIN_SPAN : RUNIN_MIN_SPAN)));
         if (useRunIn && !envRun && c->runinSkip > 0) { c->runinSkip--; useRunIn = false; }
+        // How long the stream remembers a missing dictionary is read off the DATA before the first try (what the engine has learnt
+        // from calls given up -- above -- stays as the second opinion): over 32 blocks spread over the span, the share of the bytes of
+        // a block's first 1024 sequences that matches take directly from the block before it (k_dict_share: tokens only, 0.1 ms; a
+        // block's head leans on the block before it more than its body: whole blocks give 0.065 / 0.077 where the heads give 0.29 /
+        // 0.32).  Measured (scripts/runin_share.py): the reference's linked text 0.291-0.292 (forgotten after 5 to 12 blocks: the
+        // default run-in), the engine's own linked text 0.321-0.325 (9 to 15 blocks: the long one), Python sources written by the
+        // reference 0.19, noise with a period just under 64 KiB 0.9 (never: pointer pass).  The two text writers are 10 % apart --
+        // a threshold between them is a calibration on two generators, not a law; a stream on the wrong side of it costs what it
+        // cost before this rule (the default run-in given up once, or the long one where the default would have done).
+        if (useRunIn && !envRun) {
+            const int nS = span0 < 32 ? span0 : 32, step = span0 / nS;
+            a.segFirst = first;
+            bool sampled = hipMemsetAsync(a.linkStat + 8, 0, 8, c->stream) == hipSuccess;
+            if (sampled) launch_dict_share(a, step, nS, c->stream);
+            sampled = sampled && hipMemcpyAsync(stat + 8, a.linkStat + 8, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                      hipStreamSynchronize(c->stream) == hipSuccess;
+            (void)hipGetLastError();
+            if (sampled && stat[9] > 0) {
+                const double share = (double)stat[8] / (double)stat[9];
+                c->runinShareE6 = (int)(share * 1e6);
+                if (share >= RUNIN_SHARE_NEVER) useRunIn = false;
+                else if (share >= RUNIN_SHARE_LONG) longRun = true;
+                if (longRun && (uint64_t)span0 * per64 < 2 * RUNIN_MIN_SPAN) useRunIn = false;
+            }
+        }
         if (useRunIn) {
             // run-in length: on text the 5th to 12th block of 64 KiB is the first without a byte of the missing dictionary
             // (scripts/runin_sim.py); bigger blocks carry it further in bytes -- 256 KiB: 4 blocks, 1 MiB: 2, measured
@@ -854,6 +890,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             (void)hipGetLastError();                             // (only a failed reservation is left to swallow here)
             a.ring = nullptr; a.zeroPage = nullptr; a.runRes = nullptr; a.runCtl = nullptr; a.runInfo = nullptr; a.runDirty = nullptr;
             a.runPiece = 0; a.runIn = 0;
+            c->linkedPath = done ? (longRun ? 3 : 2) : 4;
             if (done) { link_scratch_release(c); return check_launch("decode launch"); }
             // Not finished this way (a broken block, rounds that run out, no scratch): the segments that did finish are final,
             // the one that did not has the first pass's results still; its blocks go through the passes below
@@ -877,6 +914,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // blocks are walked one after the other.  (Read per call: the tests shrink both to reach every seam.)
     const char *envPool = getenv("MI355LZ4_LINKED_POOL_BLOCKS"), *envPtr = getenv("MI355LZ4_LINKED_PTR"),
                *envSeg = getenv("MI355LZ4_LINKED_PTR_BLOCKS");
+    if (c->linkedPath != 4) c->linkedPath = 5;
     const int poolMax = envPool ? atoi(envPool) : 16384;
     const int ptrMax = (envSeg && atoi(envSeg) > 0) ? atoi(envSeg) : 4096;
     const bool usePtr = !envPtr || atoi(envPtr) != 0;

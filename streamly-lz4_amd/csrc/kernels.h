@@ -115,6 +115,7 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fet
 void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: the fetch of block a.onlyBlk alone; PtrCtl::lastOpen tells whether it is complete
 size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
+void launch_dict_share(const DecodeArgs &a, int step, int count, hipStream_t s);   // linkStat[8], [9]: bytes taken directly from the dictionary / bytes walked, over `count` blocks from a.segFirst on
 void launch_link_stat(const DecodeArgs &a, hipStream_t s);       // linkStat from result[] (the decode launchers call it themselves)
 void launch_runin_decode(const DecodeArgs &a, hipStream_t s);    // long linked stream: every piece with its run-in + the comparison
 void launch_runin_fix(const DecodeArgs &a, hipStream_t s);       // ... one round (a.runRound) of pieces to be redone

@@ -1619,6 +1619,53 @@ __global__ __launch_bounds__(256) void k_longest_stream(DecodeArgs a)
     atomicMax(&a.linkStat[3], (uint32_t)(b1 - b0));
 }
 
+// How much of a linked block's output comes DIRECTLY from the block before it: matches whose source starts in front of
+// the block (cbits/lz4.c:1883-1911).  One wavefront per SAMPLED block (blocks a.segFirst, a.segFirst + step, ...: `count` of
+// them) walks the block's first sequences -- tokens and lengths only, nothing is copied -- and adds {bytes from the
+// dictionary, bytes walked} to linkStat[8], [9].  The run-in decode reads how long a stream remembers a missing dictionary
+// off this share before its first call (api.cpp): the reference's text 0.065, the engine's own linked text 0.077, noise
+// with a period just under 64 KiB 0.5-0.9 (scripts/dict_share.py).
+#define DICT_SHARE_SEQS 1024
+__global__ __launch_bounds__(64) void k_dict_share(DecodeArgs a, int step, int count)
+{
+    const int s = (int)blockIdx.x;
+    if (s >= count) return;
+    const int blk = a.segFirst + s * step;
+    if (blk >= a.nBlocks) return;
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    if (uni(read_block_header(a, blk, data, compLen, cap)) != 0) return;
+    InWindow win;
+    win.lo = a.framed; win.hi = a.framed + a.framedLen;
+    win.load(data);
+    auto rd = [&](int pos) -> uint32_t {
+        const uint8_t *p = data + pos;
+        if (!win.covers(p, 1)) win.load(p);
+        return win.byte_at(p);
+    };
+    int ip = 0;
+    uint32_t op = 0, direct = 0;
+    for (int n = 0; n < DICT_SHARE_SEQS && ip + 3 < compLen; n++) {
+        const uint32_t t = rd(ip); ip++;
+        uint32_t lit = t >> 4;
+        if (lit == 15u) { uint32_t x; do { x = (ip < compLen) ? rd(ip) : 0u; ip++; lit += x; } while (x == 255u && ip < compLen); }
+        ip += (int)lit; op += lit;
+        if (ip + 2 > compLen) break;
+        const uint32_t off = rd(ip) | (rd(ip + 1) << 8); ip += 2;
+        uint32_t ml = t & 15u;
+        if (ml == 15u) { uint32_t x; do { x = (ip < compLen) ? rd(ip) : 0u; ip++; ml += x; } while (x == 255u && ip < compLen); }
+        ml += LZ4_MINMATCH;
+        if (off > op) direct += min(ml, off - op);
+        op += ml;
+    }
+    if (lane_id() == 0) { atomicAdd(&a.linkStat[8], direct); atomicAdd(&a.linkStat[9], op); }
+}
+
+void launch_dict_share(const DecodeArgs &a, int step, int count, hipStream_t s)
+{
+    if (a.linkStat && count > 0) hipLaunchKernelGGL(k_dict_share, dim3((unsigned)count), dim3(64), 0, s, a, step, count);
+}
+
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s)
 {
     if (a.streamFirst && a.nStreams > 0 && a.linkStat)

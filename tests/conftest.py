@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "streamly-lz4_amd")):
 
 def _decoders():
     """Decoder variants the loaded library has: 1 (sequence at a time), 2 (lane-parallel, one wavefront per block), 4 (one
-    workgroup per block; a linked call takes variant 2 under it) and, in the experiment build only (make lib-exp, MI355LZ4_LIB
+    workgroup per block, also as a linked call's first pass) and, in the experiment build only (make lib-exp, MI355LZ4_LIB
     pointing at it), 3 (token lists).  MI355LZ4_TEST_ONLY_DECODER narrows the list."""
     try:
         import streamly_lz4_amd as S

@@ -1,7 +1,7 @@
 """The workgroup-per-block decoder (decoder variant 4, csrc/decode_cu.hpp; what variant 0 picks for calls of up to 256
 independent blocks): the same bytes and the same per-block results -- the reference's negative codes included
 (cbits/lz4.c:2163) -- as the lane-parallel decoder and the oracle, on the shapes that move it between its forms:
-blocks of several segments (more than 64 KiB of output or 42 KiB of compressed bytes), lengths with one, two and many
+blocks of several segments (a segment is 32 KiB of output or 22 KiB of compressed bytes), lengths with one, two and many
 extension bytes (the parse follows two), long literal stretches inside compressible data, matches that overlap their own
 output, sources in front of a segment, tiny blocks (left to the lane-parallel decoder), corrupted blocks."""
 import random
@@ -67,7 +67,7 @@ def test_cu_decoder_odd_shapes(engine, oracle):
 
 
 def test_cu_decoder_big_blocks(engine, oracle):
-    """BlockMax1MB / BlockMax4MB sized blocks (Config.hs:109-116): 16 and 64 segments a block, sources in earlier segments."""
+    """BlockMax1MB / BlockMax4MB sized blocks (Config.hs:109-116): 32 and 128 segments a block, sources in earlier segments."""
     for n, kind in ((1 << 20, "text"), (4 << 20, "lzsynth"), ((4 << 20) - 7, "text")):
         data = oracle.gen(kind, (n + 65535) // 65536, 65536, first_block=11).tobytes()[:n]
         # text repeats itself across the block: matches reach back up to 65535 bytes, into earlier segments
@@ -100,12 +100,12 @@ def test_cu_decoder_corrupted_blocks(engine, oracle):
 
 def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
     """Variant 0: up to 256 blocks a call go to the workgroup-per-block decoder, more to the lane-parallel one (its 16 words
-    of diagnostics per block tell which ran); a linked call always takes the lane-parallel decoder."""
+    of diagnostics per block tell which ran); a linked call's first -- standalone -- pass follows the same rule."""
     import ctypes as C
     import torch
     S = pytest.importorskip("streamly_lz4_amd")
     dev = torch.device("cuda:0")
-    for nblk, linked, expect in ((100, False, True), (256, False, True), (257, False, False), (100, True, False)):
+    for nblk, linked, expect in ((100, False, True), (256, False, True), (257, False, False), (100, True, True), (300, True, False)):
         raw = oracle.gen("text", nblk, 4096, first_block=1).tobytes()
         blocks = [raw[i:i + 4096] for i in range(0, len(raw), 4096)]
         fr = _frame_ref(oracle, blocks)
@@ -137,7 +137,7 @@ def test_runin_state_decays_with_every_linked_call(engine, oracle):
     S = pytest.importorskip("streamly_lz4_amd")
     f = S.lib.mi355lz4_debug_runin_state
     f.restype = C.c_int
-    st = (C.c_int * 3)()
+    st = (C.c_int * 5)()
     data = oracle.gen("text", 8, 65536).tobytes()
     fr = oracle.frame_compress(data, 65536, 1, 8, True)                 # a linked stream far below every run-in threshold
     try:
@@ -146,9 +146,9 @@ def test_runin_state_decays_with_every_linked_call(engine, oracle):
             out, _ = engine.decompress_batch(fr, linked=True)
             assert out == data
             f(engine.ctx, st, None)
-            assert list(st) == [1, k + 1, 0], (k, list(st))
+            assert list(st)[:3] == [1, k + 1, 0], (k, list(st))
         out, _ = engine.decompress_batch(fr, linked=True)
         f(engine.ctx, st, None)
-        assert out == data and list(st) == [0, 0, 0]
+        assert out == data and list(st)[:3] == [0, 0, 0]
     finally:
         f(engine.ctx, None, (C.c_int * 3)(0, 0, 0))

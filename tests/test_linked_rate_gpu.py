@@ -250,6 +250,13 @@ def test_long_linked_stream_default_is_runin_decode(engine, slz4, oracle, monkey
         f.write(json.dumps(rec) + "\n")
     print(rec)
     assert rates["run-in (default)"] > rates["pointer pass"]
+    import ctypes as C
+    st = (C.c_int * 5)()
+    monkeypatch.delenv("MI355LZ4_LINKED_RUNIN", raising=False)
+    engine.decompress_batch_device(buf, len(fr), off, nb, torch.zeros(nb * bl, dtype=torch.uint8, device=dev), ooff, res, linked=True)
+    engine.synchronize()
+    slz4.lib.mi355lz4_debug_runin_state(engine.ctx, st, None)
+    assert list(st)[:3] == [0, 0, 0] and st[4] == 2, list(st)       # the default run-in, chosen from the sample (share st[3] / 1e6)
     # The same stream with payload bytes of three blocks corrupted: whatever the run-in decode does with it (a block that fails
     # with its dictionary sends the span to the pointer pass), results and bytes must be those of the
     # pointer pass alone -- which tests/test_parity_gpu.py holds against the oracle's codes on short streams.
@@ -278,19 +285,39 @@ def test_long_linked_stream_default_is_runin_decode(engine, slz4, oracle, monkey
     assert bool((same | ~good).all().item())
 
 
-def test_long_linked_stream_that_never_forgets(slz4, oracle):
-    """A long stream whose every block is made of the block before it (noise with a period just under 64 KiB): no run-in
-    arrives at the true dictionary, the run-in decode gives the call up for the pointer pass (chains of pieces to redo) and
-    the engine's next linked calls do not try again.  Bytes and results exact every time; an engine of its own, so that the
-    shared one keeps its defaults."""
+def _copying_stream(nb, bl=65536):
+    """(bytes, framed): a linked stream written by hand in which every block but the first is ONE match that copies the block from
+    65535 bytes back (the data is noise of period 65535) and five literals: legal LZ4, and every byte derives from the first
+    block -- a run-in from anywhere else never arrives at the true bytes.  (The reference's own compressor does not write such
+    streams: on periodic noise it finds its matches in every other block only -- the blocks in between are literals and stand
+    alone -- and on blocks that repeat the block before them with changes its 4096-entry table has lost most of the positions
+    65 000 bytes back: the sampled share stays at 0.12.)"""
     import random
+    pat = random.Random(11).randbytes(65535)
+    data = (pat * (nb * bl // 65535 + 2))[: nb * bl]
+    ml = bl - 5 - 4 - 15
+    first = b"\xf0" + b"\xff" * ((bl - 15) // 255) + bytes([(bl - 15) % 255]) + data[:bl]
+    out = [len(first).to_bytes(4, "little") + bl.to_bytes(4, "little") + first]
+    head = b"\x0f\xff\xff" + b"\xff" * (ml // 255) + bytes([ml % 255]) + b"\x50"
+    for k in range(1, nb):
+        c = head + data[(k + 1) * bl - 5:(k + 1) * bl]
+        out.append(len(c).to_bytes(4, "little") + bl.to_bytes(4, "little") + c)
+    return data, b"".join(out)
+
+
+def test_long_linked_stream_that_never_forgets(slz4, oracle):
+    """A long stream whose every block IS the block before it (_copying_stream, written by hand): no run-in arrives at the true
+    dictionary.  The engine reads that off a sample of the stream's blocks (all of their bytes come directly from the block
+    before: api.cpp, k_dict_share) and takes the pointer pass from the first call on -- without the sample the run-in decode
+    gives the first call up and the engine learns it that way.  Bytes and results exact every time (the oracle decodes a short
+    stream of the same make); an engine of its own, so that the shared one keeps its defaults."""
     import torch
     dev = torch.device("cuda:0")
     eng = slz4.Engine(0)
     bl, nb = 65536, 9472
-    pat = random.Random(11).randbytes(60000)
-    data = (pat * (nb * bl // len(pat) + 1))[: nb * bl]
-    fr = oracle.frame_compress(data, bl, 1, 8, True)
+    d6, f6 = _copying_stream(6, bl)
+    assert oracle.frame_decompress(f6, len(d6), 8, bl, True) == d6
+    data, fr = _copying_stream(nb, bl)
     offs = np.zeros(nb + 1, dtype=np.int64)
     pos = 0
     for i in range(nb):
@@ -313,8 +340,14 @@ def test_long_linked_stream_that_never_forgets(slz4, oracle):
         ms.append(round(eng.elapsed_ms(e0, e1), 3))
         assert bool((res == bl).all().item()) and torch.equal(out, src)
         del out
-    rec = {"streams": 1, "blocks": nb, "block_len": bl, "data": "noise of period 60000, reference-linked, one stream",
-           "ms_first_call_gives_up": ms[0], "ms_next_calls": ms[1:]}
+    # (straight to the pointer pass from the first call on: the sample of the stream's blocks says that it never forgets its
+    # dictionary; the engine's state stays as it was: no call was given up)
+    import ctypes as C
+    st = (C.c_int * 5)()
+    slz4.lib.mi355lz4_debug_runin_state(eng.ctx, st, None)
+    assert list(st)[:3] == [0, 0, 0] and st[3] >= 600000 and st[4] == 5, list(st)
+    rec = {"streams": 1, "blocks": nb, "block_len": bl, "data": "every block one match that copies the block before it, hand-written, one stream",
+           "sampled_dictionary_share": st[3] / 1e6, "ms_first_call": ms[0], "ms_next_calls": ms[1:]}
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
@@ -322,8 +355,9 @@ def test_long_linked_stream_that_never_forgets(slz4, oracle):
 
 def test_long_engine_written_linked_stream_takes_the_long_run_in(slz4):
     """The engine's own linked compressor takes half of a text block from the block before it (the reference's: a third), and
-    its streams forget a missing dictionary after 9 to 15 blocks instead of 5 to 12: the default run-in gives the first call
-    up (pointer pass), the engine's next calls take the long one.  Bytes and results exact every time; the rates are
+    its streams forget a missing dictionary after 9 to 15 blocks instead of 5 to 12: the default run-in would give
+    a call up (round 5: the first call of an engine, 43 ms, then 22); the engine reads the stream's kind off a sample of its blocks and
+    takes the long run-in from the first call on.  Bytes and results exact every time; the rates are
     recorded.  An engine of its own."""
     import torch
     dev = torch.device("cuda:0")
@@ -365,4 +399,10 @@ def test_long_engine_written_linked_stream_takes_the_long_run_in(slz4):
     with open(os.path.join(ROOT, "gpurun_out", "linked_rate.json"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(rec)
-    assert min(ms[1:]) < ms[0]
+    # the long run-in is taken from the FIRST call on: how long the stream remembers a dictionary is read off a sample of its
+    # blocks (api.cpp, k_dict_share), no longer learnt from a call given up (round 5: 43 ms, then 22)
+    import ctypes as C
+    st = (C.c_int * 5)()
+    slz4.lib.mi355lz4_debug_runin_state(eng.ctx, st, None)
+    assert list(st)[:3] == [0, 0, 0] and st[4] == 3, list(st)       # nothing was given up, nothing learnt; the long run-in
+    assert ms[0] < 1.5 * min(ms[1:]), ms
