@@ -252,6 +252,7 @@ static int sim_pipe(const uint8_t *src, int n, int accel)
 // Two windows per step: both probed with every position written at once (W0 then W1), finished in order, covered
 // positions take their insertion back (W1 first), the next pair starts at the end of the last selected match.
 static int LATECONTIN = 0;
+static int TABN = 4096;      // pair: table entries (the kernel: 4096; 3072 would fit 8 KiB of LDS with its tags -- round 6, five waves per SIMD)
 static int BLINDBACK = 0;
 static int SELFRUN = 0;       // pair: a position without a table candidate whose 4 bytes continue a run of the byte before it takes position - 1
 static int DROP2ND = 0;       // pair: a window with more than 16 heads verifies its primary heads (left neighbour without a candidate) first and drops what does not fit 16 groups     // pair: covered positions put the old entry back without looking whether the bucket still holds them      // pair: W0's run-continuing lanes are not written at probe time, only (if uncovered) after the selection
@@ -271,7 +272,7 @@ static int sim_pair(const uint8_t *src, int n, int accel)
             for (int w = 0; w < 2; w++) {
                 for (int l = 64 * w; l < 64 * w + 64; l++) {
                     int pos = p0 + l; valid[l] = 1;
-                    uint32_t hx = hash16(src + pos); h[l] = hx >> 8; tg[l] = (hx >> (8 - TAGBITS)) & tmask;
+                    uint32_t hx = hash16(src + pos); h[l] = ((hx >> 8) * (uint32_t)TABN) >> 12; tg[l] = (hx >> (8 - TAGBITS)) & tmask;
                     old[l] = table[h[l]]; cand[l] = old[l].pos;
                     candOk[l] = old[l].used && cand[l] < (uint32_t)pos && (old[l].tag & tmask) == tg[l] && cand[l] >= 8;
                     if (SELFRUN && !candOk[l] && pos >= 9 && src[pos] == src[pos - 1] && src[pos + 1] == src[pos] && src[pos + 2] == src[pos] && src[pos + 3] == src[pos]) { cand[l] = pos - 1; candOk[l] = 1; }
@@ -382,7 +383,7 @@ int main(int argc, char **argv)
     TAGBITS = 4; MINC = 8; RUN("cur tag4 cand>=8", sim_cur(blocks[b], bl, 1)); MINC = 0;
     TAGBITS = 4; BACKCAP = 0; RUN("cur tag4 back0", sim_cur(blocks[b], bl, 1)); BACKCAP = 16; RUN("cur tag4 back16", sim_cur(blocks[b], bl, 1)); BACKCAP = 1000; RUN("cur tag4 back-inf", sim_cur(blocks[b], bl, 1)); BACKCAP = 8;
     TAGBITS = 4; WIN = 128; RUN("cur tag4 win128", sim_cur(blocks[b], bl, 1)); WIN = 64;
-    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; BLINDBACK = 1; RUN("pair tag4 blind takeback", sim_pair(blocks[b], bl, 1)); BLINDBACK = 0; HEADCAP = 1000; SELFRUN = 1; RUN("pair tag4 self runs (offset 1)", sim_pair(blocks[b], bl, 1)); SELFRUN = 0; DROP2ND = 1; RUN("pair tag4 one round, primary heads first", sim_pair(blocks[b], bl, 1)); DROP2ND = 0; HEADCAP = 16; RUN("pair tag4 headcap16", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; HEADCAP = 1000;
+    TAGBITS = 4; HEADCAP = 32; RUN("cur tag4 headcap32", sim_cur(blocks[b], bl, 1)); HEADCAP = 48; RUN("cur tag4 headcap48", sim_cur(blocks[b], bl, 1)); HEADCAP = 32; RUN("pair tag4", sim_pair(blocks[b], bl, 1)); HEADCAP = 48; RUN("pair tag4 headcap48", sim_pair(blocks[b], bl, 1)); HEADCAP = 1000; RUN("pair tag4 no head cap", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; LATECONTIN = 1; RUN("pair tag4 late contin", sim_pair(blocks[b], bl, 1)); LATECONTIN = 0; BLINDBACK = 1; RUN("pair tag4 blind takeback", sim_pair(blocks[b], bl, 1)); BLINDBACK = 0; HEADCAP = 1000; SELFRUN = 1; RUN("pair tag4 self runs (offset 1)", sim_pair(blocks[b], bl, 1)); TABN = 3072; RUN("pair tag4 self runs, 3072 entries", sim_pair(blocks[b], bl, 1)); TABN = 2048; RUN("pair tag4 self runs, 2048 entries", sim_pair(blocks[b], bl, 1)); TABN = 4096; TAGBITS = 0; RUN("pair no tags self runs, 4096 entries", sim_pair(blocks[b], bl, 1)); TAGBITS = 4; SELFRUN = 0; DROP2ND = 1; RUN("pair tag4 one round, primary heads first", sim_pair(blocks[b], bl, 1)); DROP2ND = 0; HEADCAP = 16; RUN("pair tag4 headcap16", sim_pair(blocks[b], bl, 1)); HEADCAP = 32; HEADCAP = 1000;
     TAGBITS = 8; RUN("cur tag8", sim_cur(blocks[b], bl, 1));
     TAGBITS = 0; RUN("cur tag0", sim_cur(blocks[b], bl, 1));
     for (int tb = 4; tb <= 8; tb += 4)

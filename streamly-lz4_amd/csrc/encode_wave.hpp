@@ -60,9 +60,33 @@ __device__ __forceinline__ void tag_set(uint32_t *tags, uint32_t h, uint32_t t)
     atomicAnd(&tags[h >> 3], ~(15u << sh));
     atomicOr(&tags[h >> 3], t << sh);
 }
-#define ENC_TABLE_ENTRIES (4096 + 1024)        /* 16-bit units: 4096 positions + 4096 nibbles */
-#define ENC_TAG_DECL uint32_t *tags = (uint32_t *)(table + 4096);
-#define ENC_HT(v, h, t) const uint32_t hx_ = hash5x(v); h = hx_ >> 4; t = hx_ & 15u
+// ENC_TAB_N: positions in the table.  4096 is what ships (with the tags: 10 KiB of LDS, 16 waves per CU).  3072 (7.5 KiB: 20 waves per
+// CU, five per SIMD with at most 102 VGPRs) is round 6's occupancy experiment -- measured, not shipped: text loses 3.5 % of its
+// ratio (oracle/sim_encode2.c: 1.838 -> 1.774, below the reference's 1.806) -- see DESIGN.md 0c.
+#ifndef ENC_TAB_N
+#define ENC_TAB_N 4096
+#endif
+#define ENC_STR2_(x) #x
+#define ENC_STR_(x) ENC_STR2_(x)
+#define ENC_TAG_OFFSET_BYTES 8192              /* = ENC_TAB_N * 2, as a literal for the instruction's offset field */
+#if ENC_TAB_N != 4096
+#undef ENC_TAG_OFFSET_BYTES
+#define ENC_TAG_OFFSET_BYTES 6144
+static_assert(ENC_TAB_N == 3072, "ENC_TAB_N: 4096 or 3072");
+#endif
+#define ENC_TABLE_ENTRIES (ENC_TAB_N + ENC_TAB_N / 4)        /* 16-bit units: the positions + a nibble each */
+#define ENC_TAG_DECL uint32_t *tags = (uint32_t *)(table + ENC_TAB_N);
+// bucket << 4 | tag of a position's first five bytes
+#if ENC_TAB_N == 4096
+__device__ __forceinline__ uint32_t enc_hx(uint64_t v) { return hash5x(v); }
+#else
+__device__ __forceinline__ uint32_t enc_hx(uint64_t v)
+{
+    const uint32_t x = (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 20));     // 12 bits of bucket, 4 of tag, 4 unused
+    return ((((x >> 8) * (uint32_t)ENC_TAB_N) >> 12) << 4) | ((x >> 4) & 15u);
+}
+#endif
+#define ENC_HT(v, h, t) const uint32_t hx_ = enc_hx(v); h = hx_ >> 4; t = hx_ & 15u
 #define ENC_TAG_OK(h, t) (tag_get(tags, h) == (t))
 #define ENC_TAG_SET(h, t) tag_set(tags, h, t)
 
@@ -173,7 +197,7 @@ __device__ __forceinline__ void lds_mskor(uint32_t *w, uint32_t mask, uint32_t b
 // positions) travels in the instruction's offset field, so the word's address is the one its read already computed
 __device__ __forceinline__ void lds_mskor_tag(const void *table, uint32_t idx, uint32_t mask, uint32_t bits)
 {
-    asm volatile("ds_mskor_b32 %0, %1, %2 offset:8192" : : "v"((uint32_t)(uintptr_t)table + idx * 4u), "v"(mask), "v"(bits) : "memory");
+    asm volatile("ds_mskor_b32 %0, %1, %2 offset:" ENC_STR_(ENC_TAG_OFFSET_BYTES) : : "v"((uint32_t)(uintptr_t)table + idx * 4u), "v"(mask), "v"(bits) : "memory");
 }
 
 // v_writelane_b32: lane k of v becomes the wave-uniform x.  (This clang has no builtin for it; the LLVM intrinsic is
@@ -448,7 +472,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
     // zero the table (positions are block-relative; 0 is a real position, as in the reference)
     {
         uint32_t *t32 = (uint32_t *)table;
-        const int nd = (int)(4096 * sizeof(TabT) / 4) + 512;    // positions, then the tags
+        const int nd = (int)(ENC_TAB_N * sizeof(TabT) / 4) + ENC_TAB_N / 8;    // positions, then the tags
         for (int i = lane; i < nd; i += LZ4_WAVE) t32[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -513,6 +537,41 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
         // ===================================================================================================
         const LZ4_GLOBAL uint8_t *gsrc = as_global(src);
         auto load16 = [&](uint32_t off) -> dev_v4 { return *(const LZ4_GLOBAL dev_v4u *)(gsrc + off); };
+        // EXPERIMENT (round 6, ENC_STAGE=1; measured, not shipped -- DESIGN.md 0c, profiles/r06_encode_structural_attempt.txt): the
+        // pair form's INPUT bytes through LDS.  A scattered 16-byte request per lane keeps a CU's one texture addresser busy for 64
+        // cycles and a pair of windows makes six of them (TA busy 94 % of the kernel; one more per window: -25 %).  Three of the six
+        // ask for bytes the wave is looking at anyway -- the positions' own 8 bytes and the 64 bytes around every run head.  With
+        // the stage one aligned dword per lane (256 bytes from 8 bytes before the pair: a 16-cycle request) is written to 256 bytes
+        // of LDS behind the table, and both come out of it with aligned dword reads and a byte funnel; only the candidates' side is
+        // still scattered.  Result: requests -45 %, TA busy 94 -> 53 %, waiting 48 -> 40 % of wave cycles -- and the same time: the
+        // funnels are 35 vector instructions more per pair (+12 %), which is what the waiting had been hiding, and the 256 bytes
+        // take the 16th wave of a CU (10 KiB x 16 = all of LDS): -9 %.
+#ifndef ENC_STAGE
+#define ENC_STAGE 0
+#endif
+        uint8_t *const stage = (uint8_t *)table + ENC_TABLE_ENTRIES * sizeof(uint16_t);
+        uint32_t pfD = 0;           // the stage's dword of this lane for the pair that starts at stNext + 8 + (0..3)
+        int stNext = 0, stCur = 0;  // block-relative position of the stage's first byte: of the pair requested / of the pair in LDS
+        auto stage_request = [&](const int p) {
+            stNext = p - 8 - (int)(((uint32_t)(uintptr_t)gsrc + (uint32_t)p) & 3u);
+            const int q = stNext + 4 * lane;
+            pfD = (q < n) ? *(const LZ4_GLOBAL uint32_t *)(gsrc + q) : 0u;       // (an aligned dword with a byte of the block in it)
+        };
+        // 8 / 16 bytes at any byte offset of the stage: aligned dwords + v_alignbyte (an LDS access that is not naturally aligned
+        // costs a cycle per lane, decode_par.hpp)
+        auto stage_u64 = [&](const uint32_t addr) -> uint64_t {
+            const uint32_t *q = (const uint32_t *)(stage + (addr & ~3u));
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], sh = addr & 3u;
+            return ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+        };
+        auto stage_v4 = [&](const uint32_t addr) -> dev_v4 {
+            const uint32_t *q = (const uint32_t *)(stage + (addr & ~3u));
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], sh = addr & 3u;
+            dev_v4 r;
+            r.x = __builtin_amdgcn_alignbyte(d1, d0, sh); r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            r.z = __builtin_amdgcn_alignbyte(d3, d2, sh); r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            return r;
+        };
         const bool pipeFits = n < (1 << 24);           // a group's candidate travels in 25 bits, an end in 24
 #ifndef ENC_GROUPS
 #define ENC_GROUPS 0          // 0: adaptive; 2 / 4: one shape (measurements)
@@ -614,7 +673,7 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             uint64_t longm;                             // hit lanes whose run is at least 24 bytes long from its head: groups of two would have to extend them
         };
         auto lw_probe = [&](LW &W, const uint32_t pos, const uint64_t v8, const bool insertNow) {
-            const uint32_t hx = hash5x(v8);
+            const uint32_t hx = enc_hx(v8);
             const uint32_t tsh = (hx >> 2) & 28u;                  // (h & 7) * 4
             W.hx = hx;
             W.tmask = 15u << tsh;
@@ -686,8 +745,15 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const uint32_t j16 = (GL == 4u) ? gc4.j16 : ((uint32_t)lane & 1u) << 4;
             const uint32_t gi = (GL == 4u) ? (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0x00 /* quad_perm 0,0,0,0 */, 0xf, 0xf, true)
                                            : (uint32_t)__builtin_amdgcn_mov_dpp((int)giRaw, 0xa0 /* quad_perm 0,0,2,2 */, 0xf, 0xf, true);
-            a = load16((uint32_t)(p0w - 8) + (gi >> 25) + j16);
+            if (PAIR && ENC_STAGE) a = stage_v4((uint32_t)(p0w - 8 - stCur) + (gi >> 25) + j16);
+            else a = load16((uint32_t)(p0w - 8) + (gi >> 25) + j16);
             b = load16((gi & 0x1ffffffu) + j16);
+#ifdef ENC_EXP_EXTRA_LOAD
+            {   // experiment: one more 16-byte request per lane and window -- is the texture addresser the limit?  
+                dev_v4 x_ = load16((uint32_t)(p0w - 8) + (gi >> 25) + (j16 ^ 16u));
+                asm volatile("" : : "v"(x_.x), "v"(x_.y), "v"(x_.z), "v"(x_.w));
+            }
+#endif
         };
         auto lw_loads = [&](auto G, LW &W, const int p0w) {
             lw_fetch(G, W.gi0, p0w, W.a0, W.b0);
@@ -909,6 +975,15 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             const int p1 = p0 + LZ4_WAVE;
             const uint32_t pos0 = (uint32_t)(p0 + lane), pos1 = pos0 + 64u;
             LW W0, W1;
+            if (ENC_STAGE) {
+                // (the reads of the pair before are behind us in program order, and a wave's LDS instructions run in order)
+                ((uint32_t *)stage)[lane] = pfD;
+                stCur = stNext;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t d = (uint32_t)(p0 - stCur) + (uint32_t)lane;
+                pfV8 = stage_u64(d);
+                pfV8b = stage_u64(d + 64u);
+            }
 #ifdef ENC_STATS
             { uint32_t x = (uint32_t)pfV8 ^ (uint32_t)pfV8b; asm volatile("" : "+v"(x)); }      // the bytes have arrived
             ENC_LAP(4);
@@ -962,8 +1037,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
             go = nextP + 200 <= n && (sel0 | sel1) != 0ull;
             pfPos = -1;                                        // (the windows that follow the last pair fetch their own bytes)
             if (go) {
-                pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
-                pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + LZ4_WAVE + lane));
+                if (ENC_STAGE) stage_request(nextP);
+                else {
+                    pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + lane));
+                    pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(nextP + LZ4_WAVE + lane));
+                }
             }
             ENC_LAP(2);
             if (qCnt + (int)__builtin_popcountll(sel0) + (int)__builtin_popcountll(sel1) > LZ4_WAVE) flush_queue();
@@ -993,8 +1071,11 @@ __device__ int encode_block_wave(const uint8_t *src, int n, uint8_t *dst, int ac
                     int np = (int)p;
                     if constexpr (PAIR) {
                         // (the last 200 bytes of a block are left to the windows below)
-                        if (pfPos != np) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + lane));
-                        pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + LZ4_WAVE + lane));
+                        if (ENC_STAGE) stage_request(np);
+                        else {
+                            if (pfPos != np) pfV8 = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + lane));
+                            pfV8b = *(const LZ4_GLOBAL u64_unaligned *)(gsrc + (uint32_t)(np + LZ4_WAVE + lane));
+                        }
                         bool go = true;
                         while (go) {
                             if (shape == 4) {

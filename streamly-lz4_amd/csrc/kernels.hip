@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PE
 #ifndef ENC_LDS_PAD
 #define ENC_LDS_PAD 0
 #endif
-    __shared__ uint16_t table[ENC_TABLE_ENTRIES + ENC_LDS_PAD];   // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU
+    // positions + tags (encode_wave.hpp): 10 KiB, 16 waves per CU (the ENC_STAGE experiment's 256 bytes behind them make it 15)
+    __shared__ __attribute__((aligned(16))) uint16_t table[ENC_TABLE_ENTRIES + ENC_LDS_PAD + ((PAIR && ENC_STAGE) ? 128 : 0)];
     const int blk = (int)blockIdx.x;
     const uint64_t off = a.srcOff ? a.srcOff[blk] : (uint64_t)blk * a.blockStride;
     const int n = a.srcLen ? a.srcLen[blk] : a.uniformLen;
