@@ -159,7 +159,8 @@ def timing():
                             op += lit + ml
                         print("  block", b, "why", d[b, 0], "nPar/tailIp/tailOp", d[b, 1:4].tolist(), "expected", exp, "C", len(comp), flush=True)
                         shown += 1
-            line["nPar_mean"] = float(d[:, 1].mean())
+            line["nPar_mean"] = float((d[:, 1] & 0xffff).mean())
+            line["rounds_median"] = int(np.median(d[:, 1] >> 16))
             ok = d[:, 0] == 0
             if ok.any():
                 t = d[ok][:, 4:16]
@@ -167,7 +168,9 @@ def timing():
                 dt = ((t[:, 1:] - t[:, :-1]) & 0xffffffff) / 100.0        # us (100 MHz)
                 line["phase_us_median"] = {n: round(float(np.median(dt[:, i])), 2) for i, n in enumerate(names)}
                 line["block_us_median"] = round(float(np.median(((t[:, 11] - t[:, 0]) & 0xffffffff) / 100.0)), 2)
-                line["wave0_polls_progress"] = [int(np.median(d[ok][:, 3] >> 16)), int(np.median(d[ok][:, 3] & 0xffff))]
+                t12 = d[ok][:, 12] & 0xffff                              # the match phase: fill | rounds | gather (us)
+                f = ((d[ok][:, 3] & 0xffff) - t12) & 0xffff; r = ((d[ok][:, 3] >> 16) - (d[ok][:, 3] & 0xffff)) & 0xffff; g = ((d[ok][:, 13] & 0xffff) - (d[ok][:, 3] >> 16)) & 0xffff
+                line["matches_fill_rounds_gather_us"] = [round(float(np.median(x)) / 100.0, 2) for x in (f, r, g)]
                 line["shader_MHz"] = round(float(np.median(d[ok][:, 2] / (((t[:, 11] - t[:, 0]) & 0xffffffff) / 100.0))), 0)
             eng.set_decoder(0)
             print(line, flush=True)

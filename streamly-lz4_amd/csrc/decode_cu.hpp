@@ -28,7 +28,7 @@
 //                 to 300 matches deep, 32 768 for a run of one byte -- is resolved in 8 to 10 rounds (16) with every lane
 //                 of sixteen waves busy, whatever it looks like; then every byte is fetched from the byte its pointer
 //                 arrived at.  (The first form walked the graph match by match through done bits: 0.9 us per level.)
-//   5. flush      LDS -> global memory with aligned 16-byte stores.
+//   5. flush      LDS -> global memory with 16-byte stores.
 //   6. next       the first sequence that is not plain ends the segment.  If it is the output or table limit that ended it,
 //                 the next segment starts there; a sequence the parse does not take (a length with more than two extension bytes, an offset
 //                 of 0, a match that straddles the dictionary's end) is decoded by wave 0 with the sequential decoder and the
@@ -65,6 +65,10 @@ namespace lz4dev {
 #define CU_REDO ((int)0x80000001)   // result of a block the form leaves to the lane-parallel decoder
 #define CU_IDLE_LIMIT 2000000u   // polls without progress after which a wave gives the block up (never reached: see there)
 #define CU_TAILMAX 512u         // compressed bytes left to the sequential decoder at the block's end
+#ifndef CU_MLP
+#define CU_MLPF 2u                // ... of the pointers' first fill (four LDS words of rank record and four sequence records a quad)
+#define CU_MLP 4u                 // quads of output bytes a thread of the match phase has in flight (LDS round trips overlap within a batch)
+#endif
 #define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
 // LDS map (bytes).  [0, 33 KiB): the segment's output (during the parse: the compressed bytes, up to 47 KiB of them with their
 // padding).  [33, 97 KiB): a 16-bit source pointer per output byte (during the parse: part of T[], two bytes per compressed
@@ -538,7 +542,9 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
 
         uint2 *rec = (uint2 *)(lds + CU_OFF_REC);
         uint8_t *out = lds;
-        const uint32_t A = (uint32_t)((uintptr_t)sdst & 15u);    // LDS index of the segment's output position x is A + x
+        // (the LDS index of the segment's output position x is x: the match phase stores aligned words; the flush's 16-byte stores
+        // are as aligned in global memory as the segment's first byte happens to be)
+        constexpr uint32_t A = 0u;
 
         // ---------------- 2e. every chunk walks its sequences: counts, scan, records ----------------
         // (thread t owns chunks 2t and 2t + 1: the scan runs in chunk order; the two are walked side by side: a sequence is
@@ -683,56 +689,114 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
             // graph match by match through done bits -- eight waves polling, one to three of 64 lanes busy per step: 0.9 us a level,
             // 91-94 us of a 64 KiB segment's 134-155.
             {
-                uint32_t *ptr32 = (uint32_t *)(lds + CU_OFF_PTR);            // two pointers a word: bytes 2k and 2k + 1
+                uint2 *ptr64 = (uint2 *)(lds + CU_OFF_PTR);                  // four pointers a quad: bytes 4k .. 4k + 3
                 const uint16_t *ptr16 = (const uint16_t *)(lds + CU_OFF_PTR);
-                const uint32_t nPairs = (tailOp + 1u) / 2u;
-                for (uint32_t k = tid; k < nPairs; k += CU_THREADS) {
-                    const uint32_t x0 = 2u * k, x1 = x0 + 1u;
-                    // the sequences that hold x0 and x1: one rank record serves both (x0 is even)
-                    const uint4 rr = rk[x0 >> 6];
-                    const bool hi = (x0 & 32u) != 0u;
-                    const uint32_t m0 = (2u << (x0 & 31u)) - 1u, m1 = (2u << (x1 & 31u)) - 1u;
-                    const uint32_t i0 = rr.z + (uint32_t)__builtin_popcount(rr.x & (hi ? ~0u : m0)) + (uint32_t)__builtin_popcount(rr.y & (hi ? m0 : 0u)) - 1u;
-                    const uint32_t i1 = rr.z + (uint32_t)__builtin_popcount(rr.x & (hi ? ~0u : m1)) + (uint32_t)__builtin_popcount(rr.y & (hi ? m1 : 0u)) - 1u;
-                    const uint2 r0 = rec[i0];
-                    uint2 r1 = r0;
-                    if (i1 != i0) r1 = rec[i1];
-                    // (a record: first output byte | ..., literals -- and what came from in front of the segment -- | offset << 16)
-                    const uint32_t d0 = (r0.x & 0xffffu) + (r0.y & 0xffffu), d1 = (r1.x & 0xffffu) + (r1.y & 0xffffu);
-                    const uint32_t p0 = (x0 < d0) ? x0 : x0 - (r0.y >> 16);
-                    const uint32_t p1 = (x1 < d1 || x1 >= tailOp) ? x1 : x1 - (r1.y >> 16);
-                    ptr32[k] = p0 | (p1 << 16);
+                const uint32_t nQ = (tailOp + 3u) >> 2;
+                // (every loop of this phase is a chain of dependent LDS round trips -- ~100 ns each -- per quad, and a thread has up to
+                // eight quads: the loops are unrolled in batches, every batch's reads of one kind issued together, so that a round trip
+                // is paid per batch and not per quad.  Quads, not bytes or pairs: the fill is bound by vector issue -- a rank in the
+                // sequence starts' bit vector per quad and one add per byte, instead of a rank per byte -- and rounds and gather by LDS
+                // instructions: six per quad each)
+                constexpr uint32_t PERQ = CU_OUTMAX / 4u / CU_THREADS;        // quads per thread: 8
+                for (uint32_t m0_ = 0; m0_ < PERQ && tid + m0_ * CU_THREADS < nQ; m0_ += CU_MLPF) {
+                    uint4 rr[CU_MLPF];
+                    uint32_t ix[CU_MLPF][4];
+                    uint2 r[CU_MLPF][4];
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLPF; u++) {
+                        const uint32_t k = min(tid + (m0_ + u) * CU_THREADS, nQ - 1u);          // (a quad past the end repeats the last one)
+                        rr[u] = rk[k >> 4];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLPF; u++) {
+                        const uint32_t k = min(tid + (m0_ + u) * CU_THREADS, nQ - 1u);
+                        const uint32_t x0 = 4u * k, sh = x0 & 31u;                               // (sh <= 28: the quad's four bits lie in one word)
+                        const bool hi = (x0 & 32u) != 0u;
+                        const uint32_t w = hi ? rr[u].y : rr[u].x;
+                        // the sequence that holds x0: the starts at or before it; its neighbours': one more for every start among them
+                        ix[u][0] = rr[u].z + (hi ? (uint32_t)__builtin_popcount(rr[u].x) : 0u) + (uint32_t)__builtin_popcount(w & ((2u << sh) - 1u)) - 1u;
+                        const uint32_t nb = w >> sh;
+                        ix[u][1] = ix[u][0] + ((nb >> 1) & 1u);
+                        ix[u][2] = ix[u][1] + ((nb >> 2) & 1u);
+                        ix[u][3] = ix[u][2] + ((nb >> 3) & 1u);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLPF; u++)
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) r[u][j] = rec[ix[u][j]];
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLPF; u++) {
+                        const uint32_t k = min(tid + (m0_ + u) * CU_THREADS, nQ - 1u);
+                        uint32_t pp[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) {
+                            // (a record: first output byte | ..., literals -- and what came from in front of the segment -- | offset << 16)
+                            const uint32_t x = 4u * k + j;
+                            const uint32_t d = (r[u][j].x & 0xffffu) + (r[u][j].y & 0xffffu);
+                            pp[j] = (x < d || x >= tailOp) ? x : x - (r[u][j].y >> 16);
+                        }
+                        ptr64[k] = make_uint2(pp[0] | (pp[1] << 16), pp[2] | (pp[3] << 16));
+                    }
                 }
                 __syncthreads();
-                // rounds: a pair of pointers that does not move any more points at bytes that are in place, and is left alone
+                uint32_t tPh0 = 0u, tPh1 = 0u; int nRounds = 0;
+                if (dbg && tid == 0 && seg == 0) tPh0 = (uint32_t)wall_clock64();
+                // rounds: a quad of pointers that does not move any more points at bytes that are in place, and is left alone
                 uint32_t live = 0u;
                 {
                     uint32_t m = 0u;
-                    for (uint32_t k = tid; k < nPairs; k += CU_THREADS) live |= 1u << m++;
+                    for (uint32_t k = tid; k < nQ; k += CU_THREADS) live |= 1u << m++;
                 }
                 for (int round = 0; round < 17; round++) {
                     bool changed = false;
-                    uint32_t m = 0u;
-                    for (uint32_t k = tid; k < nPairs; k += CU_THREADS, m++) {
-                        if (!((live >> m) & 1u)) continue;
-                        const uint32_t v = ptr32[k];
-                        const uint32_t q0 = ptr16[v & 0xffffu], q1 = ptr16[v >> 16];
-                        const uint32_t nv = q0 | (q1 << 16);
-                        if (nv != v) { ptr32[k] = nv; changed = true; }
-                        else live &= ~(1u << m);
+                    for (uint32_t m0_ = 0; m0_ < PERQ && (live >> m0_) != 0u; m0_ += CU_MLP) {
+                        if (((live >> m0_) & ((1u << CU_MLP) - 1u)) == 0u) continue;
+                        uint2 v[CU_MLP];
+                        uint32_t q[CU_MLP][4];
+                        // (a quad that is not live -- settled, or past the end -- reads quad 0, which is there, and stores nothing)
+#pragma unroll
+                        for (uint32_t u = 0; u < CU_MLP; u++) v[u] = ptr64[((live >> (m0_ + u)) & 1u) ? tid + (m0_ + u) * CU_THREADS : 0u];
+#pragma unroll
+                        for (uint32_t u = 0; u < CU_MLP; u++) {
+                            q[u][0] = ptr16[v[u].x & 0xffffu]; q[u][1] = ptr16[v[u].x >> 16];
+                            q[u][2] = ptr16[v[u].y & 0xffffu]; q[u][3] = ptr16[v[u].y >> 16];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < CU_MLP; u++) {
+                            if (!((live >> (m0_ + u)) & 1u)) continue;
+                            const uint32_t n0 = q[u][0] | (q[u][1] << 16), n1 = q[u][2] | (q[u][3] << 16);
+                            if (n0 != v[u].x || n1 != v[u].y) { ptr64[tid + (m0_ + u) * CU_THREADS] = make_uint2(n0, n1); changed = true; }
+                            else live &= ~(1u << (m0_ + u));
+                        }
                     }
                     // (one word says whether any pointer moved: round r stores r + 1, and the word only grows, so a thread that
                     // reads it late -- behind a store of round r + 1 -- decides as the others did)
                     if (changed) __atomic_store_n(&misc[CM_CHANGED], (uint32_t)round + 1u, __ATOMIC_RELAXED);
                     __syncthreads();
+                    nRounds = round + 1;
                     if (__atomic_load_n(&misc[CM_CHANGED], __ATOMIC_RELAXED) < (uint32_t)round + 1u) break;
                 }
-                // every byte from the byte its pointer has arrived at (a byte in place points at itself)
-                for (uint32_t k = tid; k < nPairs; k += CU_THREADS) {
-                    const uint32_t v = ptr32[k];
-                    const uint32_t b0 = out[A + (v & 0xffffu)], b1 = out[A + (v >> 16)];
-                    out[A + 2u * k] = (uint8_t)b0;
-                    if (2u * k + 1u < tailOp) out[A + 2u * k + 1u] = (uint8_t)b1;
+                // (diagnostics: [3] = the first segment's pointer fill's end and the rounds' end as 100 MHz stamps' low halves, [1] |= rounds << 16)
+                if (dbg && tid == 0 && seg == 0) { tPh1 = (uint32_t)wall_clock64(); dbg[3] = (tPh0 & 0xffffu) | (tPh1 << 16); dbg[1] = nPar | ((uint32_t)nRounds << 16); }
+                // every byte from the byte its pointer has arrived at (a byte in place points at itself), a word at a time.  (All reads
+                // of a batch before its stores: a byte that is read is in place and a store leaves it as it is -- every other byte of
+                // a stored word is either the quad's own or in place too -- so stores never change what a later read returns; but the
+                // compiler cannot know that.  The bytes of the last quad at or behind tailOp point at themselves.)
+                for (uint32_t m0_ = 0; m0_ < PERQ && tid + m0_ * CU_THREADS < nQ; m0_ += CU_MLP) {
+                    uint2 v[CU_MLP];
+                    uint32_t bb[CU_MLP][4];
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLP; u++) v[u] = ptr64[min(tid + (m0_ + u) * CU_THREADS, nQ - 1u)];
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLP; u++) {
+                        bb[u][0] = out[v[u].x & 0xffffu]; bb[u][1] = out[v[u].x >> 16];
+                        bb[u][2] = out[v[u].y & 0xffffu]; bb[u][3] = out[v[u].y >> 16];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < CU_MLP; u++) {
+                        const uint32_t k = tid + (m0_ + u) * CU_THREADS;
+                        if (k < nQ) *(uint32_t *)&out[4u * k] = bb[u][0] | (bb[u][1] << 8) | (bb[u][2] << 16) | (bb[u][3] << 24);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -744,12 +808,8 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
             // ---------------- 5. flush the segment's output [0, tailOp) ----------------
             {
                 LZ4_GLOBAL uint8_t *gd = as_global(sdst);
-                const uint32_t total = A + tailOp;
-                for (uint32_t k = tid; k < total / 16u; k += CU_THREADS)
-                    if (k > 0u || A == 0u) *(LZ4_GLOBAL par_v4 *)(gd + 16u * k - A) = *(const par_v4 *)&out[16u * k];
-                if (A != 0u && tid < 16u - A && tid < tailOp) gd[tid] = out[A + tid];
-                for (uint32_t x = (total / 16u) * 16u + tid; x < total; x += CU_THREADS)
-                    if (x >= A && (x >= 16u || A == 0u)) gd[x - A] = out[x];
+                for (uint32_t k = tid; k < tailOp / 16u; k += CU_THREADS) *(LZ4_GLOBAL par_v4u *)(gd + 16u * k) = *(const par_v4 *)&out[16u * k];
+                for (uint32_t x = (tailOp / 16u) * 16u + tid; x < tailOp; x += CU_THREADS) gd[x] = out[x];
             }
         }
         // ---------------- 6. what comes next ----------------
