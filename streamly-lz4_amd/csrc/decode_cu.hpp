@@ -66,7 +66,7 @@ namespace lz4dev {
 #define CU_IDLE_LIMIT 2000000u   // polls without progress after which a wave gives the block up (never reached: see there)
 #define CU_TAILMAX 512u         // compressed bytes left to the sequential decoder at the block's end
 #ifndef CU_MLP
-#define CU_MLPF 2u                // ... of the pointers' first fill (four LDS words of rank record and four sequence records a quad)
+#define CU_MLPF 4u                // ... of the pointers' first fill (four LDS words of rank record and two sequence records a quad)
 #define CU_MLP 4u                 // quads of output bytes a thread of the match phase has in flight (LDS round trips overlap within a batch)
 #endif
 #define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
@@ -700,8 +700,8 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 constexpr uint32_t PERQ = CU_OUTMAX / 4u / CU_THREADS;        // quads per thread: 8
                 for (uint32_t m0_ = 0; m0_ < PERQ && tid + m0_ * CU_THREADS < nQ; m0_ += CU_MLPF) {
                     uint4 rr[CU_MLPF];
-                    uint32_t ix[CU_MLPF][4];
-                    uint2 r[CU_MLPF][4];
+                    uint32_t ix0[CU_MLPF], ix3[CU_MLPF];
+                    uint2 rlo[CU_MLPF], rhi[CU_MLPF];
 #pragma unroll
                     for (uint32_t u = 0; u < CU_MLPF; u++) {
                         const uint32_t k = min(tid + (m0_ + u) * CU_THREADS, nQ - 1u);          // (a quad past the end repeats the last one)
@@ -713,27 +713,26 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                         const uint32_t x0 = 4u * k, sh = x0 & 31u;                               // (sh <= 28: the quad's four bits lie in one word)
                         const bool hi = (x0 & 32u) != 0u;
                         const uint32_t w = hi ? rr[u].y : rr[u].x;
-                        // the sequence that holds x0: the starts at or before it; its neighbours': one more for every start among them
-                        ix[u][0] = rr[u].z + (hi ? (uint32_t)__builtin_popcount(rr[u].x) : 0u) + (uint32_t)__builtin_popcount(w & ((2u << sh) - 1u)) - 1u;
-                        const uint32_t nb = w >> sh;
-                        ix[u][1] = ix[u][0] + ((nb >> 1) & 1u);
-                        ix[u][2] = ix[u][1] + ((nb >> 2) & 1u);
-                        ix[u][3] = ix[u][2] + ((nb >> 3) & 1u);
+                        // the sequence that holds x0: the starts at or before it.  A sequence is at least four bytes long (its match is), so
+                        // at most one more starts inside the quad: two records serve its four bytes
+                        ix0[u] = rr[u].z + (hi ? (uint32_t)__builtin_popcount(rr[u].x) : 0u) + (uint32_t)__builtin_popcount(w & ((2u << sh) - 1u)) - 1u;
+                        ix3[u] = ix0[u] + (((w >> sh) & 0xeu) != 0u ? 1u : 0u);
                     }
 #pragma unroll
-                    for (uint32_t u = 0; u < CU_MLPF; u++)
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) r[u][j] = rec[ix[u][j]];
+                    for (uint32_t u = 0; u < CU_MLPF; u++) { rlo[u] = rec[ix0[u]]; rhi[u] = rec[ix3[u]]; }
 #pragma unroll
                     for (uint32_t u = 0; u < CU_MLPF; u++) {
                         const uint32_t k = min(tid + (m0_ + u) * CU_THREADS, nQ - 1u);
+                        // (a record: first output byte | ..., literals -- and what came from in front of the segment -- | offset << 16)
+                        const uint32_t sHi = (ix3[u] != ix0[u]) ? (rhi[u].x & 0xffffu) : 0xffffffffu;
+                        const uint32_t dLo = (rlo[u].x & 0xffffu) + (rlo[u].y & 0xffffu), dHi = (rhi[u].x & 0xffffu) + (rhi[u].y & 0xffffu);
+                        const uint32_t oLo = rlo[u].y >> 16, oHi = rhi[u].y >> 16;
                         uint32_t pp[4];
 #pragma unroll
                         for (uint32_t j = 0; j < 4u; j++) {
-                            // (a record: first output byte | ..., literals -- and what came from in front of the segment -- | offset << 16)
                             const uint32_t x = 4u * k + j;
-                            const uint32_t d = (r[u][j].x & 0xffffu) + (r[u][j].y & 0xffffu);
-                            pp[j] = (x < d || x >= tailOp) ? x : x - (r[u][j].y >> 16);
+                            const bool h = x >= sHi;
+                            pp[j] = (x < (h ? dHi : dLo) || x >= tailOp) ? x : x - (h ? oHi : oLo);
                         }
                         ptr64[k] = make_uint2(pp[0] | (pp[1] << 16), pp[2] | (pp[3] << 16));
                     }
