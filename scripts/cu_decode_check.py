@@ -173,7 +173,13 @@ def timing():
                 line["matches_fill_rounds_gather_us"] = [round(float(np.median(x)) / 100.0, 2) for x in (f, r, g)]
                 line["shader_MHz"] = round(float(np.median(d[ok][:, 2] / (((t[:, 11] - t[:, 0]) & 0xffffffff) / 100.0))), 0)
             eng.set_decoder(0)
-            print(line, flush=True)
+            if "brief" in args:
+                ph = line.get("phase_us_median", {})
+                print("%-8s %-9s v4 %.4f ms %6.1f GB/s  block %6.1f us  records %5.2f  matches %5.2f %s  T %.2f cands %.2f rank %.2f lit %.2f" % (
+                    kind, writer, line["variant4_ms"], line["variant4_GBps"], line.get("block_us_median", 0), ph.get("records", 0), ph.get("matches", 0),
+                    line.get("matches_fill_rounds_gather_us"), ph.get("T", 0), ph.get("cands", 0), ph.get("rank", 0), ph.get("literals", 0)), flush=True)
+            else:
+                print(line, flush=True)
 
 
 if not args or "check" in args:

@@ -66,9 +66,13 @@ namespace lz4dev {
 #define CU_IDLE_LIMIT 2000000u   // polls without progress after which a wave gives the block up (never reached: see there)
 #define CU_TAILMAX 512u         // compressed bytes left to the sequential decoder at the block's end
 #ifndef CU_MLP
-#define CU_MLPF 4u                // ... of the pointers' first fill (four LDS words of rank record and two sequence records a quad)
-#define CU_MLP 4u                 // quads of output bytes a thread of the match phase has in flight (LDS round trips overlap within a batch)
+// quads of output bytes a thread of the match phase has in flight: the LDS round trips of a batch overlap.  Measured (160 blocks of
+// 64 KiB, us: fill | rounds | gather): fill 1 / 2 / 4 quads: 4.0 / 5.6 / 6.9 (bound by vector issue: the batches' registers spill);
+// rounds and gather 1 / 2 / 4 / 8: 14.2 | 1.84, 11.5 | 1.88, 12.2 | 1.96, worse
+#define CU_MLPF 1u
+#define CU_MLP 2u
 #endif
+#define CU_SLOTS 5u               // sequences of a chunk the first walk keeps for the second (a chunk of 16 bytes has at most six)
 #define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
 // LDS map (bytes).  [0, 33 KiB): the segment's output (during the parse: the compressed bytes, up to 47 KiB of them with their
 // padding).  [33, 97 KiB): a 16-bit source pointer per output byte (during the parse: part of T[], two bytes per compressed
@@ -550,6 +554,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         // (thread t owns chunks 2t and 2t + 1: the scan runs in chunk order; the two are walked side by side: a sequence is
         // two dependent LDS reads, and this way the two chunks' reads are in flight together)
         uint32_t n2[2] = {0u, 0u}, len2[2] = {0u, 0u};
+        uint2 *walked = (uint2 *)(lds + CU_OFF_PTR);
         const uint32_t c0 = 2u * tid, c1 = 2u * tid + 1u;
         const uint32_t e0 = (c0 < nChunks) ? (uint32_t)entry[c0] : CU_NONE, e1 = (c1 < nChunks) ? (uint32_t)entry[c1] : CU_NONE;
         const uint32_t cend0 = (c0 + 1u) * CU_CHUNK, cend1 = (c1 + 1u) * CU_CHUNK;
@@ -561,41 +566,69 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                 // (a chunk that stops takes one index for the token it stops at: T[] does not know everything the walk checks, so
                 // chunks behind a stop may have entries of their own, and every stop must have an index no other chunk has --
                 // the smallest one is the segment's end)
-                if (a0) { if (s0.nxt == CU_STOP) { a0 = false; n2[0]++; } else { n2[0]++; len2[0] += s0.lit + s0.ml; q0 = s0.nxt; a0 = q0 < cend0; } }
-                if (a1) { if (s1.nxt == CU_STOP) { a1 = false; n2[1]++; } else { n2[1]++; len2[1] += s1.lit + s1.ml; q1 = s1.nxt; a1 = q1 < cend1; } }
+                // (what the walk has parsed is kept for the second one -- CU_SLOTS sequences a chunk, in the pointers' area, which is
+                // free until the match phase: a parse is ~55 instructions, and this phase is bound by instruction issue)
+                auto keep = [&](const CuSeq &sq, const uint32_t c, const uint32_t j, const uint32_t q) {
+                    if (j >= CU_SLOTS) return;
+                    if (sq.nxt == CU_STOP) walked[c * CU_SLOTS + j] = make_uint2(q, 0x80000000u | (sq.odd ? 1u : 0u));
+                    else walked[c * CU_SLOTS + j] = make_uint2(sq.litStart | (sq.off << 16), sq.lit | (sq.ml << 10) | ((sq.nxt - sq.litStart) << 20));
+                };
+                if (a0) { keep(s0, c0, n2[0], q0); if (s0.nxt == CU_STOP) { a0 = false; n2[0]++; } else { n2[0]++; len2[0] += s0.lit + s0.ml; q0 = s0.nxt; a0 = q0 < cend0; } }
+                if (a1) { keep(s1, c1, n2[1], q1); if (s1.nxt == CU_STOP) { a1 = false; n2[1]++; } else { n2[1]++; len2[1] += s1.lit + s1.ml; q1 = s1.nxt; a1 = q1 < cend1; } }
             }
         }
         uint32_t totN, totLen, seqBase, opScan;
         cu_scan_excl2(n2[0] + n2[1], len2[0] + len2[1], scanTmp, &seqBase, &opScan, &totN, &totLen);
         uint32_t myStop = 0xffffffffu, myStopIp = 0, myStopOp = 0, myStopKind = 0;
         {
-            uint32_t q0 = e0, q1 = e1;
-            uint32_t i0 = seqBase, op0 = opScan, i1 = seqBase + n2[0], op1 = opScan + len2[0];
-            bool a0 = c0 < nChunks && q0 < cend0, a1 = c1 < nChunks && q1 < cend1;
             // plain on the output side too: the source lies in the block -- or entirely in the dictionary --, the reference's
             // fast loop would not change loops (cbits/lz4.c:1818, :1858-1863), and the sequence has a slot
-            auto step = [&](const CuSeq &sq, uint32_t &q, uint32_t &i, uint32_t &op, bool &act, uint32_t cend) {
-                const uint32_t outEnd = op + sq.lit + sq.ml;
-                const int sposBlk = opBase + (int)(op + sq.lit) - (int)sq.off;       // the source, relative to the block's output
-                const bool srcOk = sposBlk >= 0 || (DICT && sposBlk >= dictLo && sposBlk + (int)sq.ml <= 0);
-                const bool ok = sq.nxt != CU_STOP && srcOk && outEnd + 64u < capSeg && i < CU_NMAX;
-                if (!ok) {
-                    if (i < myStop) {                               // (the earlier of my two chunks' stops)
-                        myStop = i; myStopIp = q; myStopOp = op;
-                        myStopKind = (sq.nxt == CU_STOP ? (sq.odd ? 1u : 0u) : (!srcOk ? 1u : 0u));   // 1: one for the sequential decoder
-                    }
-                    act = false;
-                    return;
-                }
-                rec[i] = make_uint2(op | (sq.litStart << 16), sq.lit | (sq.off << 16));
-                i++; op = outEnd; q = sq.nxt;
-                act = q < cend;
+            auto stop_at = [&](const uint32_t i, const uint32_t q, const uint32_t op, const uint32_t kind) {
+                if (i < myStop) { myStop = i; myStopIp = q; myStopOp = op; myStopKind = kind; }       // (the earlier of my two chunks' stops)
             };
-            while (a0 || a1) {
-                const CuSeq s0 = cu_parse(comp, a0 ? q0 : 0u, inLim), s1 = cu_parse(comp, a1 ? q1 : 0u, inLim);
-                if (a0) step(s0, q0, i0, op0, a0, cend0);
-                if (a1) step(s1, q1, i1, op1, a1, cend1);
-            }
+            // one sequence: false = the chunk's walk ends here
+            auto place = [&](const uint32_t litStart, const uint32_t lit, const uint32_t off, const uint32_t ml, uint32_t &i, uint32_t &op) -> bool {
+                const uint32_t outEnd = op + lit + ml;
+                const int sposBlk = opBase + (int)(op + lit) - (int)off;             // the source, relative to the block's output
+                const bool srcOk = sposBlk >= 0 || (DICT && sposBlk >= dictLo && sposBlk + (int)ml <= 0);
+                if (!(srcOk && outEnd + 64u < capSeg && i < CU_NMAX)) {
+                    // (the token: in front of the literal run's length bytes -- none below 15 literals, one below 270, else two)
+                    stop_at(i, litStart - 1u - (lit < 15u ? 0u : (lit < 270u ? 1u : 2u)), op, !srcOk ? 1u : 0u);   // 1: one for the sequential decoder
+                    return false;
+                }
+                rec[i] = make_uint2(op | (litStart << 16), lit | (off << 16));
+                i++; op = outEnd;
+                return true;
+            };
+            auto chunk = [&](const uint32_t c, const uint32_t n, uint32_t i, uint32_t op, const uint32_t cend) {
+                if (n == 0u) return;
+                uint2 w[CU_SLOTS];
+#pragma unroll
+                for (uint32_t j = 0; j < CU_SLOTS; j++) w[j] = walked[c * CU_SLOTS + min(j, n - 1u)];
+                bool act = true;
+                uint32_t q = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < CU_SLOTS; j++) {
+                    if (!(act && j < n)) continue;
+                    if (w[j].y & 0x80000000u) { stop_at(i, w[j].x, op, w[j].y & 1u); act = false; continue; }   // (a stop is the last one)
+                    const uint32_t litStart = w[j].x & 0xffffu;
+                    q = litStart + (w[j].y >> 20);
+                    act = place(litStart, w[j].y & 1023u, w[j].x >> 16, (w[j].y >> 10) & 1023u, i, op);
+                }
+                // more sequences in 16 bytes than there are slots (six tokens three bytes apart): parsed again
+                if (n > CU_SLOTS && act) {
+                    act = q < cend;
+                    while (act) {
+                        const CuSeq sq = cu_parse(comp, q, inLim);
+                        if (sq.nxt == CU_STOP) { stop_at(i, q, op, sq.odd ? 1u : 0u); break; }
+                        if (!place(sq.litStart, sq.lit, sq.off, sq.ml, i, op)) break;
+                        q = sq.nxt;
+                        act = q < cend;
+                    }
+                }
+            };
+            chunk(c0, n2[0], seqBase, opScan, cend0);
+            chunk(c1, n2[1], seqBase + n2[0], opScan + len2[0], cend1);
         }
         if (myStop != 0xffffffffu) atomicMin(&misc[CM_NPAR], myStop);
         __syncthreads();
