@@ -72,6 +72,7 @@ namespace lz4dev {
 #define CU_MLPF 1u
 #define CU_MLP 2u
 #endif
+#define CU_SWEEPS 64               // sweeps of the pointer jumping after which a thread gives the block up (to the lane-parallel decoder)
 #define CU_SLOTS 5u               // sequences of a chunk the first walk keeps for the second (a chunk of 16 bytes has at most six)
 #define CU_MINSEG 512u          // ... and a segment shorter than this is not worth the parse
 // LDS map (bytes).  [0, 33 KiB): the segment's output (during the parse: the compressed bytes, up to 47 KiB of them with their
@@ -102,7 +103,7 @@ namespace lz4dev {
 #define CU_TAB_J CU_TAB_CBITS
 // ... after the parse
 #define CU_TAB_RANK 0          // uint4[513]
-enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_CHANGED, CM_COUNT };
+enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_COUNT };
 
 // byte p of the staged segment lives at LDS offset cu_at(p)
 __device__ __forceinline__ uint32_t cu_at(uint32_t p) { return p + ((p >> CU_CHUNK_LOG) << 2); }
@@ -779,8 +780,11 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                     uint32_t m = 0u;
                     for (uint32_t k = tid; k < nQ; k += CU_THREADS) live |= 1u << m++;
                 }
-                for (int round = 0; round < 17; round++) {
-                    bool changed = false;
+                // No barrier between the sweeps: a pointer that is read late or early is an ancestor of its byte either way, a quad is
+                // done when all four of its pointers have arrived at bytes that point at themselves -- which it sees on its own --, and
+                // pointers only ever move towards the segment's start, so every thread's loop ends (a wave whose quads are done leaves
+                // the issue slots to the others).  With a barrier and a shared "something moved" word per round: 11.5 us instead of 8.6.
+                while (live != 0u) {
                     for (uint32_t m0_ = 0; m0_ < PERQ && (live >> m0_) != 0u; m0_ += CU_MLP) {
                         if (((live >> m0_) & ((1u << CU_MLP) - 1u)) == 0u) continue;
                         uint2 v[CU_MLP];
@@ -797,17 +801,15 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
                         for (uint32_t u = 0; u < CU_MLP; u++) {
                             if (!((live >> (m0_ + u)) & 1u)) continue;
                             const uint32_t n0 = q[u][0] | (q[u][1] << 16), n1 = q[u][2] | (q[u][3] << 16);
-                            if (n0 != v[u].x || n1 != v[u].y) { ptr64[tid + (m0_ + u) * CU_THREADS] = make_uint2(n0, n1); changed = true; }
+                            if (n0 != v[u].x || n1 != v[u].y) ptr64[tid + (m0_ + u) * CU_THREADS] = make_uint2(n0, n1);
                             else live &= ~(1u << (m0_ + u));
                         }
                     }
-                    // (one word says whether any pointer moved: round r stores r + 1, and the word only grows, so a thread that
-                    // reads it late -- behind a store of round r + 1 -- decides as the others did)
-                    if (changed) __atomic_store_n(&misc[CM_CHANGED], (uint32_t)round + 1u, __ATOMIC_RELAXED);
-                    __syncthreads();
-                    nRounds = round + 1;
-                    if (__atomic_load_n(&misc[CM_CHANGED], __ATOMIC_RELAXED) < (uint32_t)round + 1u) break;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // (the next sweep reads what the others have stored by now)
+                    // (sixteen sweeps resolve any segment when all waves sweep together; the bound is the loop's guaranteed exit)
+                    if (++nRounds >= CU_SWEEPS) { misc[CM_ABORT] = 1u; break; }
                 }
+                __syncthreads();
                 // (diagnostics: [3] = the first segment's pointer fill's end and the rounds' end as 100 MHz stamps' low halves, [1] |= rounds << 16)
                 if (dbg && tid == 0 && seg == 0) { tPh1 = (uint32_t)wall_clock64(); dbg[3] = (tPh0 & 0xffffu) | (tPh1 << 16); dbg[1] = nPar | ((uint32_t)nRounds << 16); }
                 // every byte from the byte its pointer has arrived at (a byte in place points at itself), a word at a time.  (All reads
