@@ -121,8 +121,9 @@ int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
  * per block: what fills the GPU when a call brings thousands of blocks), 4 = one workgroup per block (sixteen wavefronts
  * share a block's output in LDS, 32 KiB at a time: a block's latency is 1.5-2 x shorter; in a linked call it is the
  * first, standalone pass -- blocks that need their dictionary go through the second pass as ever).  Variant 0 takes
- * variant 4 for calls of up to 256 blocks (MI355LZ4_CU_BLOCKS in the environment overrides the count; 0 = never) and
- * variant 2 otherwise.
+ * variant 4 for calls of up to 256 blocks -- 512 when they hold 16 KiB of compressed bytes or more on average, none when
+ * less than 3 KiB -- and variant 2 otherwise (MI355LZ4_CU_BLOCKS = n in the environment: up to n blocks whatever their
+ * size; 0 = never).
  * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
 /* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block

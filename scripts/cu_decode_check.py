@@ -175,8 +175,8 @@ def timing():
             eng.set_decoder(0)
             if "brief" in args:
                 ph = line.get("phase_us_median", {})
-                print("%-8s %-9s v4 %.4f ms %6.1f GB/s  block %6.1f us  records %5.2f  matches %5.2f %s  T %.2f cands %.2f rank %.2f lit %.2f" % (
-                    kind, writer, line["variant4_ms"], line["variant4_GBps"], line.get("block_us_median", 0), ph.get("records", 0), ph.get("matches", 0),
+                print("%-8s %-9s v2 %.4f ms  v4 %.4f ms %6.1f GB/s  block %6.1f us  records %5.2f  matches %5.2f %s  T %.2f cands %.2f rank %.2f lit %.2f" % (
+                    kind, writer, line["variant2_ms"], line["variant4_ms"], line["variant4_GBps"], line.get("block_us_median", 0), ph.get("records", 0), ph.get("matches", 0),
                     line.get("matches_fill_rounds_gather_us"), ph.get("T", 0), ph.get("cands", 0), ph.get("rank", 0), ph.get("literals", 0)), flush=True)
             else:
                 print(line, flush=True)

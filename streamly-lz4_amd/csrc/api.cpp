@@ -643,14 +643,21 @@ static int linked_finish(mi355lz4_ctx *c)
     return check_launch("decode launch");
 }
 
-// Blocks per call up to which the workgroup-per-block decoder is taken (decoder variant 0; MI355LZ4_CU_BLOCKS overrides, 0 = never)
-static int cu_auto_blocks()
+// Whether a call of decoder variant 0 takes the workgroup-per-block decoder (decode_cu.hpp): a CU decodes a 64 KiB block in 0.09-0.11 ms
+// where a wavefront takes 0.2-0.3, but 19 wavefronts share a CU.  Measured (device-resident, ms, workgroup / wavefront form; lzsynth):
+// 64 KiB blocks: 256: 0.10 / 0.20, 512: 0.20 / 0.21, 768: 0.29 / 0.21; 16 KiB: 256: 0.045 / 0.074, 512: 0.083 / 0.075; 4 KiB: 160: 0.042 /
+// 0.037 (a workgroup's fixed costs are 28 us a block).  So: up to one block per CU when blocks are not tiny, up to two when they are big --
+// judged by the compressed bytes per block, which is all the host knows.  MI355LZ4_CU_BLOCKS = n: up to n blocks whatever their size, 0 = never.
+static bool cu_auto(int nBlocks, uint64_t framedLen)
 {
-    static const int v = [] {
+    static const int forced = [] {
         const char *e = getenv("MI355LZ4_CU_BLOCKS");
-        return e ? atoi(e) : 256;
+        return e ? atoi(e) : -1;
     }();
-    return v;
+    if (forced >= 0) return nBlocks <= forced;
+    const uint64_t avg = framedLen / (uint64_t)(nBlocks > 0 ? nBlocks : 1);
+    if (avg < 3072) return false;
+    return nBlocks <= 256 || (nBlocks <= 512 && avg >= 16384);
 }
 
 // run-in decode of long linked streams: blocks of 64 KiB of run-in, and the span (in 64 KiB) from which it is the default
@@ -713,10 +720,9 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         launch_decode_tok(a, c->stream);
     }
 #endif
-    else if (!c->stats && (c->decoder == 4 || (c->decoder == 0 && nBlocks <= cu_auto_blocks())))
-        // Calls that do not fill the GPU -- one workgroup per block instead of one wavefront (decode_cu.hpp).  A CU takes about
-        // 0.12 ms per 64 KiB of a block, a wavefront 0.2-0.3 ms, but 19 wavefronts share a CU: with more blocks than CUs the
-        // wavefronts win.  (Variant 4 forces it for any number of blocks: the tests.)  A linked call's first pass is this
+    else if (!c->stats && (c->decoder == 4 || (c->decoder == 0 && cu_auto(nBlocks, framedLen))))
+        // Calls that do not fill the GPU -- one workgroup per block instead of one wavefront (decode_cu.hpp; cu_auto above says
+        // which calls those are).  (Variant 4 forces it for any number of blocks: the tests.)  A linked call's first pass is this
         // same standalone decode (decompressChunks always asks for linked = 1, and what this engine's compressor writes are
         // independent blocks): a block that needs its dictionary fails here as it does there -- 50 us later -- and is counted.
         launch_decode_cu(a, c->stream);

@@ -1,5 +1,5 @@
 """The workgroup-per-block decoder (decoder variant 4, csrc/decode_cu.hpp; what variant 0 picks for calls of up to 256
-independent blocks): the same bytes and the same per-block results -- the reference's negative codes included
+-- big blocks: 512 -- independent blocks): the same bytes and the same per-block results -- the reference's negative codes included
 (cbits/lz4.c:2163) -- as the lane-parallel decoder and the oracle, on the shapes that move it between its forms:
 blocks of several segments (a segment is 32 KiB of output or 22 KiB of compressed bytes), lengths with one, two and many
 extension bytes (the parse follows two), long literal stretches inside compressible data, matches that overlap their own
@@ -99,15 +99,18 @@ def test_cu_decoder_corrupted_blocks(engine, oracle):
 
 
 def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
-    """Variant 0: up to 256 blocks a call go to the workgroup-per-block decoder, more to the lane-parallel one (its 16 words
+    """Variant 0 (api.cpp, cu_auto): calls of up to 256 blocks -- 512 when the blocks hold 16 KiB of compressed bytes or more on
+    average, none when less than 3 KiB -- go to the workgroup-per-block decoder, the others to the lane-parallel one (the 16 words
     of diagnostics per block tell which ran); a linked call's first -- standalone -- pass follows the same rule."""
     import ctypes as C
     import torch
     S = pytest.importorskip("streamly_lz4_amd")
     dev = torch.device("cuda:0")
-    for nblk, linked, expect in ((100, False, True), (256, False, True), (257, False, False), (100, True, True), (300, True, False)):
-        raw = oracle.gen("text", nblk, 4096, first_block=1).tobytes()
-        blocks = [raw[i:i + 4096] for i in range(0, len(raw), 4096)]
+    cases = ((100, 16384, False, True), (256, 16384, False, True), (257, 16384, False, False), (100, 16384, True, True),
+             (300, 16384, True, False), (512, 65536, False, True), (513, 65536, False, False), (100, 4096, False, False))
+    for nblk, bl, linked, expect in cases:
+        raw = oracle.gen("text", nblk, bl, first_block=1).tobytes()
+        blocks = [raw[i:i + bl] for i in range(0, len(raw), bl)]
         fr = _frame_ref(oracle, blocks)
         offs, pos = [], 0
         for _ in range(nblk):
@@ -115,8 +118,8 @@ def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
             pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
         buf = torch.frombuffer(bytearray(fr), dtype=torch.uint8).to(dev)
         boff = torch.tensor(offs + [pos], dtype=torch.int64, device=dev)
-        ooff = torch.arange(0, (nblk + 1) * 4096, 4096, dtype=torch.int64, device=dev)
-        out = torch.zeros(nblk * 4096, dtype=torch.uint8, device=dev)
+        ooff = torch.arange(0, (nblk + 1) * bl, bl, dtype=torch.int64, device=dev)
+        out = torch.zeros(nblk * bl, dtype=torch.uint8, device=dev)
         res = torch.zeros(nblk, dtype=torch.int32, device=dev)
         dbg = torch.zeros(nblk * 16, dtype=torch.int32, device=dev)
         S.lib.mi355lz4_debug_cu(engine.ctx, C.c_void_p(dbg.data_ptr()))
@@ -125,9 +128,9 @@ def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
             engine.synchronize()
         finally:
             S.lib.mi355lz4_debug_cu(engine.ctx, None)
-        assert out.cpu().numpy().tobytes() == raw and bool((res == 4096).all())
+        assert out.cpu().numpy().tobytes() == raw and bool((res == bl).all())
         ran = bool((dbg.view(nblk, 16)[:, 15] != 0).any().item())       # [15]: the clock at the block's end
-        assert ran == expect, (nblk, linked, ran)
+        assert ran == expect, (nblk, bl, linked, ran)
 
 
 def test_runin_state_decays_with_every_linked_call(engine, oracle):
