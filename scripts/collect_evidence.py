@@ -21,7 +21,8 @@ names = {"bench_roundtrip.json": "bench_roundtrip.json", "bench_random256k.json"
          "bench_roundtrip_8GiB.json": "bench_roundtrip_8GiB.json", "linked_runin_decode.txt": "linked_runin_decode.txt",
          "cu_decode_small_calls.jsonl": "cu_decode_small_calls.jsonl", "cu_decode_kernel_stats.csv": "cu_decode_kernel_stats.csv",
          "cu_decode_lzsynth_pmc_instmix.txt": "cu_decode_lzsynth_pmc_instmix.txt", "cu_decode_text_pmc_instmix.txt": "cu_decode_text_pmc_instmix.txt",
-         "decode_own_vs_reference_written.txt": "decode_own_vs_reference_written.txt", "multi_device_rehearsal.jsonl": "multi_device_rehearsal.jsonl"}
+         "decode_own_vs_reference_written.txt": "decode_own_vs_reference_written.txt", "multi_device_rehearsal.jsonl": "multi_device_rehearsal.jsonl",
+         "cu_decode_crossover.txt": "cu_decode_crossover.txt", "runin_dictionary_share.txt": "runin_dictionary_share.txt"}
 files = []
 for src, dst in names.items():
     p = os.path.join(E, src)

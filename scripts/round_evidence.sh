@@ -51,6 +51,12 @@ scripts/kernel_resources.sh > "$E/kernel_resources.txt" 2>&1
 for k in lzsynth text; do bash scripts/pmc_cu.sh $k > "$E/cu_decode_${k}_pmc_instmix.txt" 2>&1; done
 python3 scripts/par_stats_ref.py lzsynth 16384 2>/dev/null | grep -v amdgpu > "$E/decode_own_vs_reference_written.txt"
 python3 scripts/multi_device_rate.py 256 2>/dev/null | grep '^{' > "$E/multi_device_rehearsal.jsonl"
+# which calls take the workgroup form (api.cpp, cu_auto): both forms at the call shapes either side of the rule
+{ for n in 256 512 768; do echo "== 64 KiB blocks, $n a call"; python3 scripts/cu_decode_check.py time brief blocks=$n 2>/dev/null | grep -v amdgpu | cut -c1-72; done
+  for n in 256 512; do echo "== 16 KiB blocks, $n a call"; python3 scripts/cu_decode_check.py time brief blocks=$n bl=16384 2>/dev/null | grep -v amdgpu | cut -c1-72; done
+  echo "== 4 KiB blocks, 160 a call"; python3 scripts/cu_decode_check.py time brief blocks=160 bl=4096 2>/dev/null | grep -v amdgpu | cut -c1-72; } > "$E/cu_decode_crossover.txt"
+# the dictionary share a linked call samples before it picks its run-in (api.cpp, k_dict_share), for the streams it has to tell apart
+python3 scripts/runin_share.py 2>/dev/null | grep share > "$E/runin_dictionary_share.txt"
 # issue rate of integer vector instructions (section 0 of DESIGN.md prices the decoder with these)
 [ -x scripts/micro/valu_rate.bin ] && scripts/micro/valu_rate.bin > "$E/valu_issue_rate.txt" 2>&1
 # `python3 bench.py --gpus 2` on its own (the script starts its ranks as a child process), rehearsed on this one GPU over gloo
