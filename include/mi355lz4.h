@@ -123,7 +123,8 @@ int mi355lz4_set_segments(mi355lz4_ctx *ctx, int segs);
  * first, standalone pass -- blocks that need their dictionary go through the second pass as ever).  Variant 0 takes
  * variant 4 for calls of up to 256 blocks -- 512 when they hold 16 KiB of compressed bytes or more on average, none when
  * less than 3 KiB -- and variant 2 otherwise (MI355LZ4_CU_BLOCKS = n in the environment: up to n blocks whatever their
- * size; 0 = never).
+ * size; 0 = never); under variant 0 the kernel itself hands a block that saves less than a sixteenth of its size to the
+ * lane-parallel decoder (long literal runs end that form's segments), under variant 4 it does not.
  * Tuning/ablation knob; results are identical.  Any other value: MI355LZ4_E_ARG. */
 int mi355lz4_set_decoder(mi355lz4_ctx *ctx, int variant);
 /* on != 0: the compress calls treat the blocks of a call as consecutive blocks of ONE stream and use block

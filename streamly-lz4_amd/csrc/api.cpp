@@ -697,7 +697,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.ptrBad = nullptr;
     a.asyncGate = 0;
     a.onlyBlk = -1;
-    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.cuDbg = c->cuDbg;
+    a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.cuDbg = c->cuDbg; a.cuBail = c->decoder == 0;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
@@ -1824,7 +1824,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
-    a.cuDbg = nullptr;
+    a.cuDbg = nullptr; a.cuBail = 0;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     if (s->dictLen) {

@@ -234,13 +234,14 @@ __device__ __forceinline__ void cu_wave_copy(uint8_t *out, uint32_t d, uint32_t 
 // Decode one block with the whole workgroup.  All arguments uniform; dict / dictLen as in decode_block_par (DICT: the previous
 // block's output, linked streams).  Returns the block's result -- or CU_REDO -- in every thread.
 // dbg (diagnostics, may be null): [0] why the block was left to the lane-parallel decoder (0 = it was not; 2 too many
-// candidates, 3 no stop, 4 a wait without end, 5 a sequential step failed), [1] sequences of the first segment, [2] shader clocks
-// of the whole block, [3] polls << 16 | polls with progress of wave 0 in the first segment, [4..15] the 100 MHz clock at the first
+// candidates, 3 no stop, 4 sweeps without end, 5 a sequential step failed, 6 segments that end after a few KiB again and again:
+// `bail`), [1] sequences of the first segment | sweeps of its pointer jumping << 16, [2] shader clocks of the whole block, [3] the
+// low halves of the 100 MHz clock behind the first segment's pointer fill and behind its sweeps, [4..15] the 100 MHz clock at the first
 // segment's phase boundaries, [14] = start of the first step behind it, [15] = end of the block.
 // (forced inline: out of line, `lds` is a generic pointer and every LDS access a flat one -- measured 3-4 x on the parse)
 template <bool DICT>
 __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict, uint32_t dictLen,
-                               const uint8_t *bufLo, const uint8_t *bufHi, uint8_t *lds, uint32_t *dbg = nullptr)
+                               const uint8_t *bufLo, const uint8_t *bufHi, uint8_t *lds, uint32_t *dbg = nullptr, bool bail = false)
 {
     int dbgAt = 4;
     auto stamp = [&]() {
@@ -851,6 +852,9 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         __syncthreads();                                          // (the segment's output is in global memory; nobody reads misc[] or the LDS output any more)
         ipBase += (int)tailIp; opBase += (int)tailOp;
         if (seg == 0) { dbgAt = 14; stamp(); }                    // [14] flushed
+        // (bail: the caller takes blocks that do not suit this form -- segments that end after a few KiB, at a literal run of
+        // hundreds of bytes, again and again -- back to the lane-parallel decoder: a segment's fixed costs are ~30 us)
+        if (bail && seg >= 7 && (uint32_t)opBase < (uint32_t)(seg + 1) * 2048u && (uint32_t)(srcLen - ipBase) > 4096u) { redo = true; why = 6; }
         // a sequence the parse does not take, or a segment that took nothing: one sequence by the sequential decoder
         if (tailKind == 1u || nPar == 0u) seqMode = 1;
     }

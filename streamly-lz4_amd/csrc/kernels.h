@@ -70,6 +70,7 @@ struct DecodeArgs {
     int32_t *tokCnt;
     // diagnostics of the workgroup-per-block decoder (mi355lz4_debug_cu): 16 words per block, null = off
     uint32_t *cuDbg;
+    int cuBail;                 // workgroup-per-block decoder: leave blocks that do not suit it (hardly compressible; long literal runs) to the lane-parallel one at once (decoder variant 0; variant 4 keeps them)
 };
 
 struct EncodeArgs {

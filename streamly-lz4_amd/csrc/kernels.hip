@@ -566,9 +566,14 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu(DecodeArgs a)
     const uint8_t *data = nullptr;
     int compLen = 0, cap = 0;
     int r = uni(read_block_header(a, blk, data, compLen, cap));
-    if (r == 0)
+    // A block that hardly compresses is literal runs of hundreds of bytes: every one of them ends a segment (the parse follows two
+    // extension bytes) and is copied by one wave, which is what the lane-parallel decoder does without the segments' fixed costs
+    // (160 blocks of 64 KiB, ms, wavefront / workgroup form: ratio 1.00: 0.045 / 0.070; text at acceleration 64, ratio 1.01: 0.53 / 1.44;
+    // lzsynth at 64, 1.03: 0.45 / 0.83; text at 16, ratio 1.14: 0.45 / 0.29 -- from there on the workgroup form is the faster one).
+    if (r == 0 && a.cuBail && (int64_t)uni(compLen) * 16 > (int64_t)uni(cap) * 15) r = CU_REDO;
+    else if (r == 0)
         r = decode_block_cu<false>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), nullptr, 0, a.framed, a.framed + a.framedLen, lds,
-                                   a.cuDbg ? a.cuDbg + 16 * (size_t)blk : nullptr);
+                                   a.cuDbg ? a.cuDbg + 16 * (size_t)blk : nullptr, a.cuBail != 0);
     if (threadIdx.x == 0) a.result[blk] = r;
 }
 

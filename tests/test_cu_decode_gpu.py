@@ -101,15 +101,19 @@ def test_cu_decoder_corrupted_blocks(engine, oracle):
 def test_cu_decoder_is_the_default_for_small_calls_only(engine, oracle):
     """Variant 0 (api.cpp, cu_auto): calls of up to 256 blocks -- 512 when the blocks hold 16 KiB of compressed bytes or more on
     average, none when less than 3 KiB -- go to the workgroup-per-block decoder, the others to the lane-parallel one (the 16 words
-    of diagnostics per block tell which ran); a linked call's first -- standalone -- pass follows the same rule."""
+    of diagnostics per block tell which ran); a linked call's first -- standalone -- pass follows the same rule; and a block that
+    saves less than a sixteenth of its size is handed on by the kernel itself (long literal runs end that form's segments)."""
     import ctypes as C
     import torch
     S = pytest.importorskip("streamly_lz4_amd")
     dev = torch.device("cuda:0")
     cases = ((100, 16384, False, True), (256, 16384, False, True), (257, 16384, False, False), (100, 16384, True, True),
-             (300, 16384, True, False), (512, 65536, False, True), (513, 65536, False, False), (100, 4096, False, False))
+             (300, 16384, True, False), (512, 65536, False, True), (513, 65536, False, False), (100, 4096, False, False),
+             (100, -65536, False, False))            # (blocks that hardly compress -- here: not at all -- are left to the lane-parallel decoder by the kernel)
     for nblk, bl, linked, expect in cases:
-        raw = oracle.gen("text", nblk, bl, first_block=1).tobytes()
+        kind = "text" if bl > 0 else "random"
+        bl = abs(bl)
+        raw = oracle.gen(kind, nblk, bl, first_block=1).tobytes()
         blocks = [raw[i:i + bl] for i in range(0, len(raw), bl)]
         fr = _frame_ref(oracle, blocks)
         offs, pos = [], 0
