@@ -7,8 +7,26 @@ import numpy as np, torch, streamly_lz4_amd as S
 from oracle.oracle import Oracle
 O = Oracle(); eng = S.Engine(0)
 nblk, BL = 160, 65536
-for kind, accel in (("lzsynth", 65537), ("random", 1), ("lzsynth", 1), ("text", 64), ("text", 16), ("text", 8), ("text", 4), ("text", 2), ("lzsynth", 16), ("lzsynth", 64)):
-    raw = O.gen(kind, nblk, BL, first_block=300).tobytes()
+for kind, accel in (("lzsynth", 65537), ("random", 1), ("lzsynth", 1), ("text", 64), ("text", 16), ("text", 8), ("text", 4), ("text", 2), ("lzsynth", 16), ("lzsynth", 64), ("zeros", 1), ("period7", 1), ("period300", 1), ("runs", 1), ("runs2", 1), ("runs3", 1)):
+    if kind == "zeros":
+        raw = bytes(nblk * BL)
+    elif kind.startswith("period"):
+        import random
+        pat = random.Random(5).randbytes(int(kind[6:])); raw = (pat * (nblk * BL // len(pat) + 1))[: nblk * BL]
+    elif kind in ("runs2", "runs3"):   # 64 / 200 random bytes, then a run of 530 to 1500 / 100 to 700 equal bytes (matches with three length bytes / two)
+        import random
+        rr = random.Random(7); parts = []
+        while sum(map(len, parts)) < nblk * BL:
+            parts.append(rr.randbytes(64 if kind == "runs2" else 200)); parts.append(bytes([rr.randrange(256)]) * (rr.randrange(530, 1500) if kind == "runs2" else rr.randrange(100, 700)))
+        raw = b"".join(parts)[: nblk * BL]
+    elif kind == "runs":            # runs of 40 to 4000 equal bytes between 8 random ones
+        import random
+        rr = random.Random(6); parts = []
+        while sum(map(len, parts)) < nblk * BL:
+            parts.append(rr.randbytes(8)); parts.append(bytes([rr.randrange(256)]) * rr.randrange(40, 4000))
+        raw = b"".join(parts)[: nblk * BL]
+    else:
+        raw = O.gen(kind, nblk, BL, first_block=300).tobytes()
     blocks = [raw[i:i + BL] for i in range(0, len(raw), BL)]
     out_ = []
     for b in blocks:
