@@ -203,28 +203,33 @@ def small_call_rates(S, eng, torch, dev, src, BL, kind, accel, with_cpu):
     L = S.lib
     u8p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     cap = NB * (S.compress_bound(BL) + 8)
-    host_t = torch.empty(U, dtype=torch.uint8); framed_t = torch.empty(cap, dtype=torch.uint8); out_t = torch.empty(U, dtype=torch.uint8)
-    host_t.copy_(src[:U].cpu())
-    ptrs = (u8p * NB)(*[C.cast(host_t.data_ptr() + i * BL, u8p) for i in range(NB)])
-    lens = np.full(NB, BL, dtype=np.int32)
-    fl = np.zeros(NB, dtype=np.int32); st = np.zeros(NB, dtype=np.int32); bl = np.zeros(NB, dtype=np.int32)
-    olen, dlen, got = C.c_size_t(), C.c_size_t(), C.c_int()
-    hc = hd = 1e9
-    for _ in range(7):
-        t0 = time.perf_counter()
-        rc = L.mi355lz4_compress_batch(eng.ctx, ptrs, lens.ctypes.data_as(i32p), NB, accel, 8, C.cast(framed_t.data_ptr(), u8p), cap,
-                                       C.byref(olen), fl.ctypes.data_as(i32p), st.ctypes.data_as(i32p))
-        t1 = time.perf_counter()
-        rc2 = L.mi355lz4_decompress_batch(eng.ctx, C.cast(framed_t.data_ptr(), u8p), olen.value, 8, 0, 0, None, 0,
-                                          C.cast(out_t.data_ptr(), u8p), U, C.byref(dlen), bl.ctypes.data_as(i32p), NB, C.byref(got))
-        t2 = time.perf_counter()
-        if rc != 0 or rc2 != 0 or dlen.value != U:
-            r["host_to_host"] = {"error": (L.mi355lz4_last_error() or b"").decode()}
-            return r
-        hc, hd = min(hc, t1 - t0), min(hd, t2 - t1)
-    if not torch.equal(out_t, host_t):
-        sys.exit("bench.py: small-call host round trip mismatch")
-    r["host_to_host"] = {"compress_ms": round(hc * 1e3, 4), "decompress_ms": round(hd * 1e3, 4), "memory": "pageable"}
+    for memory in ("pageable", "pinned"):
+        # (pinned: page-locked caller buffers, what a binding that allocates its arrays through the engine gets -- no staging copies)
+        host_t = torch.empty(U, dtype=torch.uint8); framed_t = torch.empty(cap, dtype=torch.uint8); out_t = torch.empty(U, dtype=torch.uint8)
+        if memory == "pinned":
+            host_t, framed_t, out_t = host_t.pin_memory(), framed_t.pin_memory(), out_t.pin_memory()
+        host_t.copy_(src[:U].cpu())
+        ptrs = (u8p * NB)(*[C.cast(host_t.data_ptr() + i * BL, u8p) for i in range(NB)])
+        lens = np.full(NB, BL, dtype=np.int32)
+        fl = np.zeros(NB, dtype=np.int32); st = np.zeros(NB, dtype=np.int32); bl = np.zeros(NB, dtype=np.int32)
+        olen, dlen, got = C.c_size_t(), C.c_size_t(), C.c_int()
+        hc = hd = 1e9
+        key = "host_to_host" if memory == "pageable" else "host_to_host_pinned"
+        for _ in range(7):
+            t0 = time.perf_counter()
+            rc = L.mi355lz4_compress_batch(eng.ctx, ptrs, lens.ctypes.data_as(i32p), NB, accel, 8, C.cast(framed_t.data_ptr(), u8p), cap,
+                                           C.byref(olen), fl.ctypes.data_as(i32p), st.ctypes.data_as(i32p))
+            t1 = time.perf_counter()
+            rc2 = L.mi355lz4_decompress_batch(eng.ctx, C.cast(framed_t.data_ptr(), u8p), olen.value, 8, 0, 0, None, 0,
+                                              C.cast(out_t.data_ptr(), u8p), U, C.byref(dlen), bl.ctypes.data_as(i32p), NB, C.byref(got))
+            t2 = time.perf_counter()
+            if rc != 0 or rc2 != 0 or dlen.value != U:
+                r[key] = {"error": (L.mi355lz4_last_error() or b"").decode()}
+                return r
+            hc, hd = min(hc, t1 - t0), min(hd, t2 - t1)
+        if not torch.equal(out_t, host_t):
+            sys.exit("bench.py: small-call host round trip mismatch")
+        r[key] = {"compress_ms": round(hc * 1e3, 4), "decompress_ms": round(hd * 1e3, 4), "memory": memory}
     if with_cpu:
         from oracle import oracle as orc
         hostb = host_t.numpy()

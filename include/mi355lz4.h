@@ -221,7 +221,12 @@ int mi355lz4_index_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t fra
  * H2D of group i+1, the kernels of group i and D2H of group i-1 overlap on
  * separate streams.  Caller buffers that are page-locked (hipHostMalloc /
  * hipHostRegister) are handed to the DMA engines directly; pageable ones are
- * staged through pinned slots by a small copy pool (MI355LZ4_COPY_THREADS). */
+ * staged through pinned slots by a small copy pool (MI355LZ4_COPY_THREADS).
+ * A call of one or two groups has no other group to hide its staging behind:
+ * its staging copies go in two pieces, the DMA engine moving one while the
+ * pool copies the other (MI355LZ4_STAGE_PIECES overrides the count).  10 MiB
+ * of 64 KiB blocks, decompress: 0.57 ms from pageable buffers, 0.43 ms from
+ * page-locked ones (the kernel: 0.10 ms). */
 
 /* Compress nBlocks host arrays into one dense framed stream in framedOut
  * (capacity cap).  blockFramedLen[i] (optional) = headerKind + compLen of
