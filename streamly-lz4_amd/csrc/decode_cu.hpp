@@ -336,20 +336,32 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         if (seg) dbgAt = 16;                                     // (the stamps are the first segment's)
 
         // ---------------- 1. stage ----------------
-        for (uint32_t i = tid; i < (C + 64u + 15u) / 16u; i += CU_THREADS) {
-            const uint8_t *q = ssrc + 16u * i;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (16u * i < C) {
-                if (q >= bufLo && q + 16 <= bufHi) {
-                    const par_v4 x = *(const LZ4_GLOBAL par_v4u *)q;
-                    w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
-                } else {
-                    for (int k = 0; k < 16; k++)
-                        if (q + k >= bufLo && q + k < bufHi) w[k >> 2] |= (uint32_t)as_global(q)[k] << (8 * (k & 3));
+        // (a thread has at most two pieces of 16 bytes -- 22 KiB + 64 over 1024 threads --: both are requested before either is stored)
+        {
+            uint32_t w[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            const uint32_t nPieces = (C + 64u + 15u) / 16u;
+#pragma unroll
+            for (uint32_t u = 0; u < 2u; u++) {
+                const uint32_t i = tid + u * CU_THREADS;
+                const uint8_t *q = ssrc + 16u * i;
+                if (i < nPieces && 16u * i < C) {
+                    if (q >= bufLo && q + 16 <= bufHi) {
+                        const par_v4 x = *(const LZ4_GLOBAL par_v4u *)q;
+                        w[u][0] = x.x; w[u][1] = x.y; w[u][2] = x.z; w[u][3] = x.w;
+                    } else {
+                        for (int k = 0; k < 16; k++)
+                            if (q + k >= bufLo && q + k < bufHi) w[u][k >> 2] |= (uint32_t)as_global(q)[k] << (8 * (k & 3));
+                    }
                 }
             }
-            uint32_t *d = (uint32_t *)(comp + cu_at(16u * i));   // (16 bytes never straddle a chunk's padding)
-            d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+#pragma unroll
+            for (uint32_t u = 0; u < 2u; u++) {
+                const uint32_t i = tid + u * CU_THREADS;
+                if (i < nPieces) {
+                    uint32_t *d = (uint32_t *)(comp + cu_at(16u * i));   // (16 bytes never straddle a chunk's padding)
+                    d[0] = w[u][0]; d[1] = w[u][1]; d[2] = w[u][2]; d[3] = w[u][3];
+                }
+            }
         }
         for (uint32_t c = tid; c < NCH; c += CU_THREADS) { entry[c] = (uint16_t)CU_NONE; cbits[c] = 0u; cbits1[c] = 0u; }
         if (tid < CU_NODES) { mark[tid] = 0; }
@@ -509,8 +521,10 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         stamp();                                                 // [7] candidates, list
 
         // ---------------- 2c. one wave: the nodes reachable from node 0 ----------------
+        // (a list over nSuper super-chunks is at most nSuper nodes long: 2^levels >= nSuper + 1 hops reach its end)
+        const int levels = min((int)CU_LEVELS, 32 - __builtin_clz(nSuper));
         if (wave == 0) {
-            for (int l = 1; l < CU_LEVELS; l++) {
+            for (int l = 1; l < levels; l++) {
                 const uint16_t *Jp = J + (l - 1) * CU_NODES;
                 uint16_t *Jn = J + l * CU_NODES;
                 uint32_t v[CU_NODES / LZ4_WAVE];
@@ -522,7 +536,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
             }
             if (lane == 0) mark[0] = 1;
             wave_fence();
-            for (int l = CU_LEVELS - 1; l >= 0; l--) {
+            for (int l = levels - 1; l >= 0; l--) {
                 const uint16_t *Jl = J + l * CU_NODES;
                 uint32_t m[CU_NODES / LZ4_WAVE], t[CU_NODES / LZ4_WAVE];
 #pragma unroll
