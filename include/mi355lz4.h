@@ -176,7 +176,10 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * (cbits/lz4.c:2322-2359); blocks must be given in stream order.  Blocks that
  * decode on their own (everything this engine's compressor emits) are final
  * after the parallel kernel; blocks that reach into their predecessor are
- * resolved by a second, data-parallel pass: short runs of them by a wave per
+ * resolved by a second, data-parallel pass: up to 512 big blocks (512 KiB
+ * and more: BlockMax1MB / BlockMax4MB streams) by a workgroup each against a
+ * guess of their dictionary, pass after pass until the guesses stand (DESIGN.md
+ * 0c: scratch 64 KiB per block), short runs of them by a wave per
  * run, spans of 576 MiB and more by the run-in decode (pieces of the span,
  * each decoded from a few blocks in front of it and checked against what the
  * piece in front wrote, DESIGN.md 0b: scratch two blocks per piece, at most
@@ -189,7 +192,8 @@ int mi355lz4_compact_device(mi355lz4_ctx *ctx, const uint8_t *slots, size_t slot
  * (read per call; for tests and measurements): MI355LZ4_LINKED_RUNS,
  * MI355LZ4_LINKED_RUNIN (0 = never, 1 = always), MI355LZ4_LINKED_RUNIN_PIECE,
  * MI355LZ4_LINKED_RUNIN_BLOCKS, MI355LZ4_LINKED_RUNIN_SPIN (polls a piece waits for the piece in front of it inside a launch),
- * MI355LZ4_LINKED_PTR, MI355LZ4_LINKED_PTR_BLOCKS, MI355LZ4_LINKED_POOL_BLOCKS.
+ * MI355LZ4_LINKED_PTR, MI355LZ4_LINKED_PTR_BLOCKS, MI355LZ4_LINKED_POOL_BLOCKS,
+ * MI355LZ4_LINKED_BIG (0 = never the big-block path; n = blocks from n KiB on).
  * replaces: decompressChunk, Internal/LZ4.hs:291-336. */
 int mi355lz4_decompress_batch_device(mi355lz4_ctx *ctx, const uint8_t *framed, uint64_t framedLen,
                                      const uint64_t *blockOff, int nBlocks, int headerKind, int fixedUncomp,

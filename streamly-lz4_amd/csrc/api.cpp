@@ -426,7 +426,7 @@ extern "C" int mi355lz4_debug_stats(mi355lz4_ctx *c, int enable, unsigned long l
 // Diagnostic hook (not part of the public header): the run-in decode's adaptive state {runinLong, runinLongOk, runinSkip} and, in
 // get[3], the dictionary share the last linked call sampled (millionths; -1: none) and, in get[4], how the last linked call was
 // finished: 0 no block needed its dictionary, 1 short runs walked, 2 run-in decode, 3 long run-in decode, 4 run-in decode given up
-// and the lists/pointer passes, 5 the lists/pointer passes (or the walk) at once.  get (may be null, 5 ints) receives it; set (may
+// and the lists/pointer passes, 5 the lists/pointer passes (or the walk) at once, 6 big blocks by the workgroup form against guessed dictionaries.  get (may be null, 5 ints) receives it; set (may
 // be null, 3 ints) replaces the state.  Lets a test drive default -> long -> skip -> probe.
 extern "C" int mi355lz4_debug_runin_state(mi355lz4_ctx *c, int *get, const int *set)
 {
@@ -698,6 +698,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     a.asyncGate = 0;
     a.onlyBlk = -1;
     a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0; a.cuDbg = c->cuDbg; a.cuBail = c->decoder == 0;
+    a.cuSnap = nullptr; a.cuFlags = nullptr; a.cuRes = nullptr; a.cuPass = 0;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     const size_t nFlags = streamFirst ? (size_t)(nStreams > 0 ? nStreams : 1) : 1;
@@ -709,6 +710,29 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         a.linkStat = (uint32_t *)c->linkBuf.p;
         HIP_TRY(hipMemsetAsync(a.linkStat, 0, 32, c->stream));
         HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
+    }
+    // Big linked blocks (the path behind the first pass, below): armed here, so that the first launch goes straight on with that
+    // path's pass 1 for the blocks that do not decode on their own.  What the host knows beforehand is the compressed size.
+    bool bigPre = false;
+    {
+        const char *envBig = getenv("MI355LZ4_LINKED_BIG");
+        const long bigKiB = envBig ? atol(envBig) : 512;
+        const bool plainBig = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS") &&
+                              !getenv("MI355LZ4_LINKED_RUNIN") && !getenv("MI355LZ4_LINKED_ASYNC");
+        if (linked && bigKiB > 0 && plainBig && !streamFirst && !splitOk && !deferEnd && lookBack == 0 && !dict0 && c->decoder == 0 &&
+            !c->stats && c->linkedAsyncCap <= 0 && nBlocks >= 2 && nBlocks <= 512 && cu_auto(nBlocks, framedLen) &&
+            framedLen / (uint64_t)nBlocks >= (uint64_t)bigKiB * 1024u / 4u) {
+            const size_t metaBytes = 65536 + ((size_t)nBlocks * 2 + 4) * sizeof(uint32_t);
+            if (dev_reserve(c->ptrBuf, (size_t)nBlocks * 65536u) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0 &&
+                hipMemsetAsync(c->tolMeta.p, 0, metaBytes, c->stream) == hipSuccess) {
+                uint8_t *meta = (uint8_t *)c->tolMeta.p;
+                a.zeroPage = meta; a.cuSnap = (uint8_t *)c->ptrBuf.p;
+                a.cuFlags = (uint32_t *)(meta + 65536); a.cuRes = (int32_t *)(meta + 65536 + ((size_t)nBlocks + 4) * sizeof(uint32_t));
+                a.cuPass = 1;
+                bigPre = true;
+            }
+            (void)hipGetLastError();
+        }
     }
     if (c->decoder == 1)
         launch_decode_seq(a, c->stream);
@@ -754,6 +778,42 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     if (first < 0 || last >= nBlocks || first > last) {
         link_scratch_release(c);          // the first pass is in flight on linkBuf: the next linked call must be ordered behind it
         return fail(MI355LZ4_E_HIP, "decompress: bad failure range %d..%d", first, last);
+    }
+    // Big blocks (BlockMax1MB / BlockMax4MB streams, Config.hs:109-116), few enough for a CU each: every dependent block by the
+    // workgroup-per-block decoder against a GUESS of its dictionary -- zeros, then what its predecessor's last 64 KiB were a pass ago --
+    // until a pass changes none of those (kernels.hip, k_decode_cu_linked).  A block of 1 MiB forgets a wrong dictionary long before
+    // its end, so two passes do as a rule, and the first of them has been made by the first launch (bigPre, above).
+    // MI355LZ4_LINKED_BIG = 0: never; = n: blocks from n KiB on (default 512: smaller blocks' ends still carry the wrong dictionary,
+    // pass after pass).  Anything the form cannot take (a failing block, CU_REDO, snapshots that do not settle in BIG_PASSES)
+    // leaves the call to the passes below: the results so far live in scratch.
+    if (bigPre) {
+        const char *envBig = getenv("MI355LZ4_LINKED_BIG");
+        const long bigKiB = envBig ? atol(envBig) : 512;
+        if (!a.asyncGate && (uint64_t)stat[4] >= (uint64_t)bigKiB * 1024u) {
+#define BIG_PASSES 6
+#define BIG_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { link_scratch_release(c); return fail(MI355LZ4_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+            bool settled = false;
+            int passes = 0;
+            for (int pass = 1; pass <= BIG_PASSES && !settled; pass++) {
+                a.cuPass = pass; passes = pass;
+                launch_cu_linked(a, pass > 1, c->stream);
+                if (hipGetLastError() != hipSuccess) break;
+                if (pass == 1) continue;                                  // (every snapshot is new after the first pass)
+                BIG_TRY(hipMemcpyAsync(stat + 10, a.cuFlags, 8, hipMemcpyDeviceToHost, c->stream));
+                BIG_TRY(hipStreamSynchronize(c->stream));
+                if (stat[11] != 0) break;                                 // a block this form cannot take
+                settled = stat[10] == 0;
+            }
+            if (settled) {
+                launch_cu_publish(a, c->stream);
+                c->linkedPath = 6; c->runinShareE6 = passes;              // (diagnostics: path 6 reports its passes where the others report the sampled share)
+                link_scratch_release(c);
+                return check_launch("decode launch");
+            }
+#undef BIG_TRY
+            (void)hipGetLastError();
+        }
+        a.zeroPage = nullptr; a.cuSnap = nullptr; a.cuFlags = nullptr; a.cuRes = nullptr; a.cuPass = 0;
     }
     // Few dependent blocks, in short runs (stat[5] = longest run of blocks without output): every run is walked by a
     // wave of its own with the exact decoder and its dictionary; no lists, no pointers.  MI355LZ4_LINKED_RUNS = longest run
@@ -1870,7 +1930,7 @@ extern "C" int LZ4_decompress_safe_continue(LZ4_streamDecode_t *p, const char *s
     a.tolPool = nullptr; a.tolRegions = 0; a.tolPer = 0; a.tolCounter = nullptr; a.tolRegion = a.tolCount = a.tolSize = nullptr;
     a.linkStat = nullptr; a.segFirst = 0; a.segEnd = 1; a.ptr = nullptr; a.ptrCap = 0; a.ptrCtl = nullptr;
     a.ptrBad = nullptr; a.asyncGate = 0; a.onlyBlk = -1; a.tokList = nullptr; a.tokCnt = nullptr; a.runList = nullptr; a.runCap = 0;
-    a.cuDbg = nullptr; a.cuBail = 0;
+    a.cuDbg = nullptr; a.cuBail = 0; a.cuSnap = nullptr; a.cuFlags = nullptr; a.cuRes = nullptr; a.cuPass = 0;
     a.ring = nullptr; a.ringStride = 0; a.zeroPage = nullptr; a.runPiece = 0; a.runIn = 0; a.runSpin = 0; a.runRound = 0;
     a.runRes = nullptr; a.runInfo = nullptr; a.runDirty = nullptr; a.runCtl = nullptr;
     if (s->dictLen) {

@@ -104,7 +104,7 @@ namespace lz4dev {
 #define CU_TAB_J CU_TAB_CBITS
 // ... after the parse
 #define CU_TAB_RANK 0          // uint4[513]
-enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_COUNT };
+enum { CM_OVERFLOW, CM_NPAR, CM_TAIL_IP, CM_TAIL_OP, CM_TAIL_KIND, CM_ABORT, CM_RESULT, CM_NEXT_IP, CM_NEXT_OP, CM_DIFF, CM_COUNT };
 
 // byte p of the staged segment lives at LDS offset cu_at(p)
 __device__ __forceinline__ uint32_t cu_at(uint32_t p) { return p + ((p >> CU_CHUNK_LOG) << 2); }
@@ -242,7 +242,7 @@ __device__ __forceinline__ void cu_wave_copy(uint8_t *out, uint32_t d, uint32_t 
 // (forced inline: out of line, `lds` is a generic pointer and every LDS access a flat one -- measured 3-4 x on the parse)
 template <bool DICT>
 __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, uint8_t *dst, int cap, const uint8_t *dict, uint32_t dictLen,
-                               const uint8_t *bufLo, const uint8_t *bufHi, uint8_t *lds, uint32_t *dbg = nullptr, bool bail = false)
+                               const uint8_t *bufLo, const uint8_t *bufHi, uint8_t *lds, uint32_t *dbg = nullptr, bool bail = false, int again = 0)
 {
     int dbgAt = 4;
     auto stamp = [&]() {
@@ -273,6 +273,7 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
     // (Called from ONE place, at the top of the loop below, and the decoder's body is expanded once inside a loop of two
     // passes: every further expansion of it costs the kernel 2000 instructions and its registers.)
     int seqMode = 0;
+    uint32_t sameRun = 0u;                                       // (again) output bytes in a row that came out as they were
     auto sequential = [&]() {
         __threadfence_block();
         __syncthreads();
@@ -862,8 +863,17 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
             // ---------------- 5. flush the segment's output [0, tailOp) ----------------
             {
                 LZ4_GLOBAL uint8_t *gd = as_global(sdst);
-                for (uint32_t k = tid; k < tailOp / 16u; k += CU_THREADS) *(LZ4_GLOBAL par_v4u *)(gd + 16u * k) = *(const par_v4 *)&out[16u * k];
-                for (uint32_t x = (tailOp / 16u) * 16u + tid; x < tailOp; x += CU_THREADS) gd[x] = out[x];
+                uint32_t d = 0u;                                  // (again: does the segment differ from what the decode before this one left here?)
+                for (uint32_t k = tid; k < tailOp / 16u; k += CU_THREADS) {
+                    const par_v4 v = *(const par_v4 *)&out[16u * k];
+                    if (again > 0) { const par_v4 o = *(const LZ4_GLOBAL par_v4u *)(gd + 16u * k); d |= (v.x ^ o.x) | (v.y ^ o.y) | (v.z ^ o.z) | (v.w ^ o.w); }
+                    *(LZ4_GLOBAL par_v4u *)(gd + 16u * k) = v;
+                }
+                for (uint32_t x = (tailOp / 16u) * 16u + tid; x < tailOp; x += CU_THREADS) {
+                    if (again > 0) d |= (uint32_t)(gd[x] ^ out[x]);
+                    gd[x] = out[x];
+                }
+                if (d) misc[CM_DIFF] = 1u;
             }
         }
         // ---------------- 6. what comes next ----------------
@@ -871,6 +881,16 @@ __device__ __forceinline__ int decode_block_cu(const uint8_t *src, int srcLen, u
         __syncthreads();                                          // (the segment's output is in global memory; nobody reads misc[] or the LDS output any more)
         ipBase += (int)tailIp; opBase += (int)tailOp;
         if (seg == 0) { dbgAt = 14; stamp(); }                    // [14] flushed
+        // `again` (> 0: what this block decoded to the last time, with another dictionary; the bytes are still in dst): once 64 KiB in a
+        // row have come out the same, everything behind them will -- no match reaches further back, the dictionary is out of reach,
+        // and where the sequences lie does not depend on the bytes -- and the block is done.  (A step of the sequential decoder is not
+        // compared: the count starts again behind it.)
+        if (again > 0) {
+            const bool same = nPar > 0u && misc[CM_DIFF] == 0u && tailKind != 1u;
+            __syncthreads();                                      // (misc[] is cleared by the next segment's first step)
+            sameRun = same ? sameRun + tailOp : 0u;
+            if (sameRun >= 65536u && (uint32_t)opBase >= 65536u) { result = again; finished = true; }
+        }
         // (bail: the caller takes blocks that do not suit this form -- segments that end after a few KiB, at a literal run of
         // hundreds of bytes, again and again -- back to the lane-parallel decoder: a segment's fixed costs are ~30 us)
         if (bail && seg >= 7 && (uint32_t)opBase < (uint32_t)(seg + 1) * 2048u && (uint32_t)(srcLen - ipBase) > 4096u) { redo = true; why = 6; }

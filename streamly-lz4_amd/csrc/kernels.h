@@ -71,6 +71,13 @@ struct DecodeArgs {
     // diagnostics of the workgroup-per-block decoder (mi355lz4_debug_cu): 16 words per block, null = off
     uint32_t *cuDbg;
     int cuBail;                 // workgroup-per-block decoder: leave blocks that do not suit it (hardly compressible; long literal runs) to the lane-parallel one at once (decoder variant 0; variant 4 keeps them)
+    // big linked blocks by the workgroup-per-block decoder (launch_cu_linked): every dependent block decoded with a guess of its
+    // dictionary -- zeros in pass 1, from pass 2 on a snapshot of the last 64 KiB its predecessor decoded to in the pass before --
+    // until no snapshot changes any more
+    uint8_t *cuSnap;            // [nBlocks][65536]
+    uint32_t *cuFlags;          // [0] snapshots that changed in the last launch_cu_tails, [1] blocks the form cannot take, [2 + k] block k's snapshot changed
+    int32_t *cuRes;             // [nBlocks] results of the passes (published by the caller when the snapshots have settled)
+    int cuPass;
 };
 
 struct EncodeArgs {
@@ -116,6 +123,8 @@ void launch_linked_resolve_b(const DecodeArgs &a, hipStream_t s);   // data: fet
 void launch_linked_fetch_block(const DecodeArgs &a, hipStream_t s);  // data: the fetch of block a.onlyBlk alone; PtrCtl::lastOpen tells whether it is complete
 size_t ptr_ctl_last_open_offset();
 void launch_longest_stream(const DecodeArgs &a, hipStream_t s);   // linkStat[3]
+void launch_cu_linked(const DecodeArgs &a, bool decode, hipStream_t s);   // one pass over the dependent blocks (a.cuPass; decode = false: the first launch has made it), then the snapshots
+void launch_cu_publish(const DecodeArgs &a, hipStream_t s);      // a.cuRes -> a.result for the dependent blocks
 void launch_dict_share(const DecodeArgs &a, int step, int count, hipStream_t s);   // linkStat[8], [9]: bytes taken directly from the dictionary / bytes walked, over `count` blocks from a.segFirst on
 void launch_link_stat(const DecodeArgs &a, hipStream_t s);       // linkStat from result[] (the decode launchers call it themselves)
 void launch_runin_decode(const DecodeArgs &a, hipStream_t s);    // long linked stream: every piece with its run-in + the comparison

@@ -575,6 +575,92 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu(DecodeArgs a)
         r = decode_block_cu<false>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), nullptr, 0, a.framed, a.framed + a.framedLen, lds,
                                    a.cuDbg ? a.cuDbg + 16 * (size_t)blk : nullptr, a.cuBail != 0);
     if (threadIdx.x == 0) a.result[blk] = r;
+    // A linked call of big blocks (a.cuRes armed by the caller, launch_cu_linked below): a block that did not decode on its own is,
+    // as a rule, one that needs its dictionary -- pass 1 of that path (the block against 64 KiB of zeros) follows at once, while the
+    // stream's first block, which decodes on its own, is still at work.  (The redo launch still reports the exact code in result[].)
+    if (a.cuRes && blk > 0 && r == CU_REDO && !(a.cuBail && (int64_t)uni(compLen) * 16 > (int64_t)uni(cap) * 15)) {
+        __syncthreads();
+        const int r2 = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), a.zeroPage, 65536u, a.framed,
+                                            a.framed + a.framedLen, lds, nullptr, false, 0);
+        if (threadIdx.x == 0) {
+            a.cuRes[blk] = r2;
+            if (r2 < 65536 && blk + 1 < a.nBlocks) atomicAdd(&a.cuFlags[1], 1u);
+        }
+    }
+}
+
+// ---- big linked blocks (a stream of BlockMax1MB / BlockMax4MB blocks, Config.hs:109-116, written with a dictionary carried from block
+// to block, cbits/lz4.c:1608-1636): the workgroup form with a GUESSED dictionary.  A block of 1 MiB forgets a wrong dictionary long
+// before its end (text: after 5 to 12 times 64 KiB), so its last 64 KiB -- all its successor can see of it -- come out right even when its
+// own dictionary was wrong.  Pass 1 decodes every dependent block against 64 KiB of zeros, every later pass against a snapshot of what its
+// predecessor's last 64 KiB were after the pass before, and when a pass changes no snapshot, every block has been decoded against its
+// predecessor's final bytes: by induction from the stream's first block, which needs no dictionary, all of them are right.  The caller
+// (api.cpp) bounds the passes and falls back to the pointer pass; results go to a.cuRes and are published at the end.
+__global__ __launch_bounds__(CU_THREADS) void k_decode_cu_linked(DecodeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[CU_LDS_BYTES];
+    const int blk = (int)blockIdx.x;
+    if (uni(a.result[blk]) >= 0) return;                                 // decoded on its own in the first pass: final
+    if (blk == 0) { if (threadIdx.x == 0) atomicAdd(&a.cuFlags[1], 1u); return; }   // (a first block that needs a dictionary: not this path's)
+    if (a.cuPass > 2 && uni(a.cuFlags[2 + blk - 1]) == 0u) return;      // the dictionary it was decoded against last time still stands
+    const uint8_t *data = nullptr;
+    int compLen = 0, cap = 0;
+    int r = uni(read_block_header(a, blk, data, compLen, cap));
+    if (r == 0)
+        r = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), a.cuPass == 1 ? a.zeroPage : a.cuSnap + (size_t)(blk - 1) * 65536u,
+                                  65536u, a.framed, a.framed + a.framedLen, lds, nullptr, false,
+                                  (a.cuPass > 1 && uni(a.cuRes[blk]) >= 65536) ? uni(a.cuRes[blk]) : 0);      // (from the second pass on: stop where the bytes repeat the pass before)
+    if (threadIdx.x == 0) {
+        a.cuRes[blk] = r;
+        if (r < 65536 && blk + 1 < a.nBlocks) atomicAdd(&a.cuFlags[1], 1u);      // an error, CU_REDO, or a block too short to be a whole dictionary
+    }
+}
+
+// the last 64 KiB of every block -> its snapshot; [2 + k] = whether that changed the snapshot, [0] = how many did
+__global__ __launch_bounds__(1024) void k_cu_tails(DecodeArgs a)
+{
+    const int blk = (int)blockIdx.x;
+    if (blk + 1 >= a.nBlocks) return;                                    // (nobody looks at the last block's)
+    const int32_t r = a.result[blk] >= 0 ? a.result[blk] : a.cuRes[blk];
+    __shared__ uint32_t diff;
+    if (threadIdx.x == 0) diff = 0u;
+    __syncthreads();
+    uint32_t d = 0u;
+    if (r >= 65536) {
+        const uint8_t *tail = a.out + a.outOff[blk] + (size_t)r - 65536u;
+        uint8_t *snap = a.cuSnap + (size_t)blk * 65536u;
+        for (uint32_t i = threadIdx.x * 16u; i < 65536u; i += 1024u * 16u) {
+            const par_v4 v = *(const par_v4u *)(tail + i), o = *(const par_v4 *)(snap + i);
+            d |= (v.x ^ o.x) | (v.y ^ o.y) | (v.z ^ o.z) | (v.w ^ o.w);
+            *(par_v4 *)(snap + i) = v;
+        }
+    }
+    if (d) atomicOr(&diff, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ch = (diff != 0u || a.cuPass == 1) ? 1u : 0u;
+        a.cuFlags[2 + blk] = ch;
+        if (ch) atomicAdd(&a.cuFlags[0], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cu_publish(DecodeArgs a)
+{
+    const int blk = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (blk < a.nBlocks && a.result[blk] < 0) a.result[blk] = a.cuRes[blk];
+}
+
+void launch_cu_linked(const DecodeArgs &a, bool decode, hipStream_t s)
+{
+    if (a.nBlocks <= 0) return;
+    hipMemsetAsync(a.cuFlags, 0, 4, s);
+    if (decode) hipLaunchKernelGGL(k_decode_cu_linked, dim3((unsigned)a.nBlocks), dim3(CU_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_cu_tails, dim3((unsigned)a.nBlocks), dim3(1024), 0, s, a);
+}
+
+void launch_cu_publish(const DecodeArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cu_publish, dim3((unsigned)((a.nBlocks + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_decode_cu(const DecodeArgs &a, hipStream_t s)

@@ -9,6 +9,8 @@ void launch_decode_seq(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_decode_par(const DecodeArgs &, unsigned long long *, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_decode_cu(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 void launch_dict_share(const DecodeArgs &, int, int, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_cu_linked(const DecodeArgs &, bool, hipStream_t) { UNREACHABLE_LAUNCH; }
+void launch_cu_publish(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 #ifdef MI355LZ4_EXPERIMENTS
 void launch_decode_tok(const DecodeArgs &, hipStream_t) { UNREACHABLE_LAUNCH; }
 #endif

@@ -159,3 +159,68 @@ def test_runin_state_decays_with_every_linked_call(engine, oracle):
         assert out == data and list(st)[:3] == [0, 0, 0]
     finally:
         f(engine.ctx, None, (C.c_int * 3)(0, 0, 0))
+
+
+def _linked_device_call(S, engine, fr, nblk, bl, raw_len):
+    """(bytes, results, path) of one device-resident linked call over a framed stream of nblk blocks of bl bytes (the last may be short)"""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda:0")
+    offs, pos = [], 0
+    for _ in range(nblk):
+        offs.append(pos)
+        pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+    buf = torch.frombuffer(bytearray(fr), dtype=torch.uint8).to(dev)
+    boff = torch.tensor(offs + [pos], dtype=torch.int64, device=dev)
+    ooff = torch.arange(0, (nblk + 1) * bl, bl, dtype=torch.int64, device=dev)
+    out = torch.zeros(nblk * bl, dtype=torch.uint8, device=dev)
+    res = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    engine.decompress_batch_device(buf, len(fr), boff, nblk, out, ooff, res, linked=True)
+    engine.synchronize()
+    st = (C.c_int * 5)()
+    S.lib.mi355lz4_debug_runin_state(engine.ctx, st, None)
+    return out.cpu().numpy().tobytes()[:raw_len], res.cpu().tolist(), st[4]
+
+
+def test_big_linked_blocks_by_the_workgroup_form(engine, oracle, monkeypatch):
+    """A linked stream of BlockMax1MB-sized blocks (Config.hs:109-116; written with the dictionary carried from block to block,
+    cbits/lz4.c:1608-1636): every dependent block by the workgroup-per-block decoder against a guess of its dictionary, pass after
+    pass until the guesses stand (api.cpp path 6, kernels.hip k_decode_cu_linked).  Bytes and results are the input's and those of
+    the pointer pass (MI355LZ4_LINKED_BIG=0); a corrupted block, and a stream whose blocks never forget their dictionary, leave the
+    call to that pass with the same results."""
+    S = pytest.importorskip("streamly_lz4_amd")
+    monkeypatch.delenv("MI355LZ4_LINKED_BIG", raising=False)
+    for bl, nblk, kind in ((1 << 20, 24, "text"), (4 << 20, 5, "text"), (512 << 10, 40, "text")):
+        raw = oracle.gen(kind, nblk * bl // 65536, 65536, first_block=21).tobytes()[: nblk * bl - 777]     # (a ragged last block)
+        fr = oracle.frame_compress(raw, bl, 1, 8, True)
+        out, res, path = _linked_device_call(S, engine, fr, nblk, bl, len(raw))
+        assert path == 6, (bl, path)
+        assert out == raw and res == [bl] * (nblk - 1) + [bl - 777]
+        monkeypatch.setenv("MI355LZ4_LINKED_BIG", "0")
+        out0, res0, path0 = _linked_device_call(S, engine, fr, nblk, bl, len(raw))
+        monkeypatch.delenv("MI355LZ4_LINKED_BIG")
+        assert path0 != 6 and out0 == raw and res0 == res
+        # a corrupted block in the middle: the same results either way (the codes are the exact path's)
+        bad = bytearray(fr)
+        pos = 0
+        for _ in range(nblk // 2):
+            pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+        clen = int.from_bytes(fr[pos:pos + 4], "little")
+        bad[pos + 8 + clen // 2: pos + 8 + clen // 2 + 40] = b"\xff" * 40        # (length fields that run on and on)
+        bad[pos + 8 + 100: pos + 8 + 104] = b"\x0f\x00\x00\x00"                # (and a match with offset 0 near the block's start)
+        o1, r1, p1 = _linked_device_call(S, engine, bytes(bad), nblk, bl, len(raw))
+        monkeypatch.setenv("MI355LZ4_LINKED_BIG", "0")
+        o0, r0, p0 = _linked_device_call(S, engine, bytes(bad), nblk, bl, len(raw))
+        monkeypatch.delenv("MI355LZ4_LINKED_BIG")
+        assert r1 == r0, (bl, p1, [(i, a, b) for i, (a, b) in enumerate(zip(r1, r0)) if a != b])
+        assert p1 != 6 or all(x >= 65536 for x in r1[:-1]), (bl, p1)    # (a failing block sends the call to the exact passes)
+        good = [i for i, x in enumerate(r0) if x > 0 and all(y > 0 for y in r0[:i + 1])]
+        assert all(o1[i * bl:(i + 1) * bl] == o0[i * bl:(i + 1) * bl] for i in good)
+    # blocks that never forget: every 1 MiB block is the block before it, shifted (one long match out of the dictionary, then itself)
+    import random
+    bl, nblk = 1 << 20, 12
+    pat = random.Random(3).randbytes(65000)
+    raw = (pat * (nblk * bl // len(pat) + 1))[: nblk * bl]
+    fr = oracle.frame_compress(raw, bl, 1, 8, True)
+    out, res, path = _linked_device_call(S, engine, fr, nblk, bl, len(raw))
+    assert out == raw and res == [bl] * nblk, path
