@@ -22,7 +22,7 @@ names = {"bench_roundtrip.json": "bench_roundtrip.json", "bench_random256k.json"
          "cu_decode_small_calls.jsonl": "cu_decode_small_calls.jsonl", "cu_decode_kernel_stats.csv": "cu_decode_kernel_stats.csv",
          "cu_decode_lzsynth_pmc_instmix.txt": "cu_decode_lzsynth_pmc_instmix.txt", "cu_decode_text_pmc_instmix.txt": "cu_decode_text_pmc_instmix.txt",
          "decode_own_vs_reference_written.txt": "decode_own_vs_reference_written.txt", "multi_device_rehearsal.jsonl": "multi_device_rehearsal.jsonl",
-         "cu_decode_crossover.txt": "cu_decode_crossover.txt", "runin_dictionary_share.txt": "runin_dictionary_share.txt", "cu_decode_lowratio.txt": "cu_decode_lowratio.txt"}
+         "cu_decode_crossover.txt": "cu_decode_crossover.txt", "runin_dictionary_share.txt": "runin_dictionary_share.txt", "cu_decode_lowratio.txt": "cu_decode_lowratio.txt", "big_linked_blocks.txt": "big_linked_blocks.txt"}
 files = []
 for src, dst in names.items():
     p = os.path.join(E, src)

@@ -57,6 +57,8 @@ python3 scripts/multi_device_rate.py 256 2>/dev/null | grep '^{' > "$E/multi_dev
   echo "== 4 KiB blocks, 160 a call"; python3 scripts/cu_decode_check.py time brief blocks=160 bl=4096 2>/dev/null | grep -v amdgpu | cut -c1-72; } > "$E/cu_decode_crossover.txt"
 # the dictionary share a linked call samples before it picks its run-in (api.cpp, k_dict_share), for the streams it has to tell apart
 python3 scripts/runin_share.py 2>/dev/null | grep share > "$E/runin_dictionary_share.txt"
+# linked streams of big blocks: the workgroup form against guessed dictionaries (api.cpp path 6) and the pointer pass
+python3 scripts/big_linked_rate.py 2>/dev/null | grep linked > "$E/big_linked_blocks.txt"
 # the two decoder forms and the default choice on streams that hardly compress, and on very compressible ones
 python3 scripts/cu_decode_lowratio.py 2>/dev/null | grep -v amdgpu > "$E/cu_decode_lowratio.txt"
 # issue rate of integer vector instructions (section 0 of DESIGN.md prices the decoder with these)
