@@ -5,9 +5,24 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "streamly-lz4_am
 import numpy as np, torch, streamly_lz4_amd as S
 from oracle.oracle import Oracle
 O = Oracle(); eng = S.Engine(0); dev = torch.device("cuda:0")
-for bl, nblk in ((1 << 20, 256), (4 << 20, 64), (512 << 10, 512)):
+cases = ((1 << 20, 256), (4 << 20, 64), (512 << 10, 512))
+big = None
+for a_ in sys.argv[1:]:                      # big_linked_rate.py [case=<block KiB>x<blocks>] [big=<KiB from which the path is taken>]
+    if a_.startswith("case="):
+        k_, n_ = a_[5:].split("x"); cases = ((int(k_) << 10, int(n_)),)
+    if a_.startswith("big="):
+        big = a_[4:]
+for bl, nblk in cases:
     raw = O.gen("text", nblk * bl // 65536, 65536, first_block=21).tobytes()
-    fr = O.frame_compress(raw, bl, 1, 8, True)
+    if "writer=engine" in sys.argv:          # the engine's own linked compressor (more of a block comes from the block before it)
+        e2 = S.Engine(0); e2.set_linked_compress(True)
+        srct = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)
+        stride = S.slot_stride(bl, 8); slots = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); flen = torch.empty(nblk, dtype=torch.int32, device=dev)
+        dense = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); doff = torch.empty(nblk + 1, dtype=torch.int64, device=dev)
+        e2.compress_batch_device(srct, nblk, bl, slots, stride, flen); e2.compact_device(slots, stride, flen, nblk, dense, nblk * stride, doff); e2.synchronize()
+        fr = dense[: int(doff[-1].item())].cpu().numpy().tobytes(); e2.close(); del slots, dense, srct
+    else:
+        fr = O.frame_compress(raw, bl, 1, 8, True)
     offs, pos = [], 0
     for _ in range(nblk):
         offs.append(pos); pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
@@ -15,7 +30,7 @@ for bl, nblk in ((1 << 20, 256), (4 << 20, 64), (512 << 10, 512)):
     boff = torch.tensor(offs + [pos], dtype=torch.int64, device=dev)
     ooff = torch.arange(0, (nblk + 1) * bl, bl, dtype=torch.int64, device=dev)
     out = torch.zeros(nblk * bl, dtype=torch.uint8, device=dev); res = torch.zeros(nblk, dtype=torch.int32, device=dev)
-    for env in (None, "0"):
+    for env in (big, "0"):
         if env is None: os.environ.pop("MI355LZ4_LINKED_BIG", None)
         else: os.environ["MI355LZ4_LINKED_BIG"] = env
         best = 1e9
