@@ -584,7 +584,7 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu(DecodeArgs a)
                                             a.framed + a.framedLen, lds, nullptr, false, 0);
         if (threadIdx.x == 0) {
             a.cuRes[blk] = r2;
-            if (r2 < 65536 && blk + 1 < a.nBlocks) atomicAdd(&a.cuFlags[1], 1u);
+            if (r2 < 0 || (r2 < 65536 && blk + 1 < a.nBlocks)) atomicAdd(&a.cuFlags[1], 1u);   // an error, CU_REDO, or a block too short to be a whole dictionary
         }
     }
 }
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu_linked(DecodeArgs a)
                                   (a.cuPass > 1 && uni(a.cuRes[blk]) >= 65536) ? uni(a.cuRes[blk]) : 0);      // (from the second pass on: stop where the bytes repeat the pass before)
     if (threadIdx.x == 0) {
         a.cuRes[blk] = r;
-        if (r < 65536 && blk + 1 < a.nBlocks) atomicAdd(&a.cuFlags[1], 1u);      // an error, CU_REDO, or a block too short to be a whole dictionary
+        if (r < 0 || (r < 65536 && blk + 1 < a.nBlocks)) atomicAdd(&a.cuFlags[1], 1u);      // an error, CU_REDO, or a block too short to be a whole dictionary
     }
 }
 

@@ -216,6 +216,20 @@ def test_big_linked_blocks_by_the_workgroup_form(engine, oracle, monkeypatch):
         assert p1 != 6 or all(x >= 65536 for x in r1[:-1]), (bl, p1)    # (a failing block sends the call to the exact passes)
         good = [i for i, x in enumerate(r0) if x > 0 and all(y > 0 for y in r0[:i + 1])]
         assert all(o1[i * bl:(i + 1) * bl] == o0[i * bl:(i + 1) * bl] for i in good)
+    # a failure in the LAST block (nobody's dictionary): the call must not be finished by this path with that block's result
+    bl, nblk = 512 << 10, 3
+    raw = oracle.gen("text", nblk * bl // 65536, 65536, first_block=5).tobytes()
+    fr = bytearray(oracle.frame_compress(raw, bl, 1, 8, True))
+    pos = 0
+    for _ in range(nblk - 1):
+        pos += 8 + int.from_bytes(fr[pos:pos + 4], "little")
+    clen = int.from_bytes(fr[pos:pos + 4], "little")
+    fr[pos + 8 + clen - 30: pos + 8 + clen] = b"\xff" * 30         # (the block's end rules cannot hold: cbits/lz4.c:1929-2151)
+    o1, r1, p1 = _linked_device_call(S, engine, bytes(fr), nblk, bl, len(raw))
+    monkeypatch.setenv("MI355LZ4_LINKED_BIG", "0")
+    o0, r0, p0 = _linked_device_call(S, engine, bytes(fr), nblk, bl, len(raw))
+    monkeypatch.delenv("MI355LZ4_LINKED_BIG")
+    assert r1 == r0 and r1[-1] < 0 and p1 != 6 and o1[: 2 * bl] == raw[: 2 * bl], (r1, r0, p1)
     # blocks that never forget: every 1 MiB block is the block before it, shifted (one long match out of the dictionary, then itself)
     import random
     bl, nblk = 1 << 20, 12
