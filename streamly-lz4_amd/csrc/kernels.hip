@@ -638,6 +638,8 @@ __global__ __launch_bounds__(1024) void k_cu_tails(DecodeArgs a)
     if (d) atomicOr(&diff, 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
+        // (a block that is no whole dictionary -- shorter than 64 KiB, or failed -- in front of a block that needs one: not this path's)
+        if (r < 65536 && a.result[blk + 1] < 0) atomicAdd(&a.cuFlags[1], 1u);
         const uint32_t ch = (diff != 0u || a.cuPass == 1) ? 1u : 0u;
         a.cuFlags[2 + blk] = ch;
         if (ch) atomicAdd(&a.cuFlags[0], 1u);

@@ -230,6 +230,30 @@ def test_big_linked_blocks_by_the_workgroup_form(engine, oracle, monkeypatch):
     o0, r0, p0 = _linked_device_call(S, engine, bytes(fr), nblk, bl, len(raw))
     monkeypatch.delenv("MI355LZ4_LINKED_BIG")
     assert r1 == r0 and r1[-1] < 0 and p1 != 6 and o1[: 2 * bl] == raw[: 2 * bl], (r1, r0, p1)
+    # a short block in the middle of big ones (resized chunks), written by the engine's linked compressor: the block behind it leans
+    # on a dictionary that is no 64 KiB of one block -- not this path's; bytes and results must be right all the same
+    parts = [oracle.gen("text", 16, 65536, first_block=31).tobytes(), oracle.gen("text", 16, 65536, first_block=31).tobytes()[500000:530000],
+             oracle.gen("text", 16, 65536, first_block=31).tobytes()[100000:1000000]]
+    e2 = S.Engine(0)
+    try:
+        e2.set_linked_compress(True)
+        fr3, flens = e2.compress_batch(parts)
+    finally:
+        e2.close()
+    import torch
+    dev = torch.device("cuda:0")
+    cap = 1 << 20
+    offs = [0, flens[0], flens[0] + flens[1], len(fr3)]
+    buf = torch.frombuffer(bytearray(fr3), dtype=torch.uint8).to(dev)
+    boff = torch.tensor(offs, dtype=torch.int64, device=dev)
+    ooff = torch.tensor([0, cap, 2 * cap, 3 * cap], dtype=torch.int64, device=dev)
+    out = torch.zeros(3 * cap, dtype=torch.uint8, device=dev)
+    res = torch.zeros(3, dtype=torch.int32, device=dev)
+    engine.decompress_batch_device(buf, len(fr3), boff, 3, out, ooff, res, linked=True)
+    engine.synchronize()
+    got = out.cpu().numpy().tobytes()
+    assert res.cpu().tolist() == [len(x) for x in parts]
+    assert all(got[i * cap:i * cap + len(x)] == x for i, x in enumerate(parts))
     # blocks that never forget: every 1 MiB block is the block before it, shifted (one long match out of the dictionary, then itself)
     import random
     bl, nblk = 1 << 20, 12
