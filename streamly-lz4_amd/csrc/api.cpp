@@ -719,7 +719,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         const long bigKiB = envBig ? atol(envBig) : 512;
         const bool plainBig = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS") &&
                               !getenv("MI355LZ4_LINKED_RUNIN") && !getenv("MI355LZ4_LINKED_ASYNC");
-        if (linked && bigKiB > 0 && plainBig && !streamFirst && !splitOk && !deferEnd && lookBack == 0 && !dict0 && c->decoder == 0 &&
+        if (linked && bigKiB > 0 && plainBig && !streamFirst && !splitOk && !deferEnd && lookBack >= 0 && !dict0 && c->decoder == 0 &&
             !c->stats && c->linkedAsyncCap <= 0 && nBlocks >= 2 && nBlocks <= 512 && cu_auto(nBlocks, framedLen) &&
             framedLen / (uint64_t)nBlocks >= (uint64_t)bigKiB * 1024u / 4u) {
             const size_t metaBytes = 65536 + ((size_t)nBlocks * 2 + 4) * sizeof(uint32_t);

@@ -578,9 +578,13 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu(DecodeArgs a)
     // A linked call of big blocks (a.cuRes armed by the caller, launch_cu_linked below): a block that did not decode on its own is,
     // as a rule, one that needs its dictionary -- pass 1 of that path (the block against 64 KiB of zeros) follows at once, while the
     // stream's first block, which decodes on its own, is still at work.  (The redo launch still reports the exact code in result[].)
-    if (a.cuRes && blk > 0 && r == CU_REDO && !(a.cuBail && (int64_t)uni(compLen) * 16 > (int64_t)uni(cap) * 15)) {
+    // (The call's first block, when blocks lie in front of the call -- a later group of a host call, a.lookBack --, has a dictionary that
+    // is FINAL: the last 64 KiB of the block in front of it; it is right after this one decode and is not looked at again.)
+    const bool prevFinal = blk == 0 && a.lookBack > 0 && a.cuRes && uni(a.result[-1]) >= 65536;
+    if (a.cuRes && (blk > 0 || prevFinal) && r == CU_REDO && !(a.cuBail && (int64_t)uni(compLen) * 16 > (int64_t)uni(cap) * 15)) {
         __syncthreads();
-        const int r2 = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), a.zeroPage, 65536u, a.framed,
+        const uint8_t *dict = prevFinal ? a.out + a.outOff[-1] + (size_t)uni(a.result[-1]) - 65536u : a.zeroPage;
+        const int r2 = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), dict, 65536u, a.framed,
                                             a.framed + a.framedLen, lds, nullptr, false, 0);
         if (threadIdx.x == 0) {
             a.cuRes[blk] = r2;
@@ -601,7 +605,12 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu_linked(DecodeArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t lds[CU_LDS_BYTES];
     const int blk = (int)blockIdx.x;
     if (uni(a.result[blk]) >= 0) return;                                 // decoded on its own in the first pass: final
-    if (blk == 0) { if (threadIdx.x == 0) atomicAdd(&a.cuFlags[1], 1u); return; }   // (a first block that needs a dictionary: not this path's)
+    if (blk == 0) {
+        // a first block that needs a dictionary: the call's (dict0) is not this path's; the block in front of the call is final, and
+        // the first launch has decoded this block against it
+        if (threadIdx.x == 0 && !(a.lookBack > 0 && a.cuRes[0] >= 65536)) atomicAdd(&a.cuFlags[1], 1u);
+        return;
+    }
     if (a.cuPass > 2 && uni(a.cuFlags[2 + blk - 1]) == 0u) return;      // the dictionary it was decoded against last time still stands
     const uint8_t *data = nullptr;
     int compLen = 0, cap = 0;

@@ -254,6 +254,15 @@ def test_big_linked_blocks_by_the_workgroup_form(engine, oracle, monkeypatch):
     got = out.cpu().numpy().tobytes()
     assert res.cpu().tolist() == [len(x) for x in parts]
     assert all(got[i * cap:i * cap + len(x)] == x for i, x in enumerate(parts))
+    # the host-buffer call: groups of 64 MiB; the second group's first block leans on the first group's last, which is final by then
+    import ctypes as C
+    bl, nblk = 1 << 20, 72
+    raw = oracle.gen("text", nblk * bl // 65536, 65536, first_block=41).tobytes()[: nblk * bl - 4321]
+    fr = oracle.frame_compress(raw, bl, 1, 8, True)
+    out, blen = engine.decompress_batch(fr, linked=True)
+    st = (C.c_int * 5)()
+    S.lib.mi355lz4_debug_runin_state(engine.ctx, st, None)
+    assert out == raw and blen == [bl] * (nblk - 1) + [bl - 4321] and st[4] == 6, st[4]
     # blocks that never forget: every 1 MiB block is the block before it, shifted (one long match out of the dictionary, then itself)
     import random
     bl, nblk = 1 << 20, 12
