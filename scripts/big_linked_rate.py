@@ -14,6 +14,8 @@ for a_ in sys.argv[1:]:                      # big_linked_rate.py [case=<block K
         big = a_[4:]
 for bl, nblk in cases:
     raw = O.gen("text", nblk * bl // 65536, 65536, first_block=21).tobytes()
+    if "data=mixz" in sys.argv:              # 32 KiB of text, 96 KiB of zeros, ...: big blocks that compress 7 x (armed behind the first pass)
+        t_ = np.frombuffer(raw, dtype=np.uint8).copy().reshape(-1, 131072); t_[:, 32768:] = 0; raw = t_.tobytes()
     if "writer=engine" in sys.argv:          # the engine's own linked compressor (more of a block comes from the block before it)
         e2 = S.Engine(0); e2.set_linked_compress(True)
         srct = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)

@@ -712,16 +712,18 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
         HIP_TRY(hipMemsetAsync(a.linkStat + 1, 0xff, 4, c->stream));
     }
     // Big linked blocks (the path behind the first pass, below): armed here, so that the first launch goes straight on with that
-    // path's pass 1 for the blocks that do not decode on their own.  What the host knows beforehand is the compressed size.
-    bool bigPre = false;
+    // path's pass 1 for the blocks that do not decode on their own.  What the host knows beforehand is the compressed size: from half
+    // the path's block size on (a stream of blocks of half that size at a ratio of 2 would otherwise pay a pass it has no use for:
+    // +0.85 ms for 512 blocks of 256 KiB); big blocks that compress better than that are armed behind the first pass (bigLate).
+    bool bigPre = false, bigEligible = false;
     {
         const char *envBig = getenv("MI355LZ4_LINKED_BIG");
         const long bigKiB = envBig ? atol(envBig) : 512;
         const bool plainBig = !getenv("MI355LZ4_LINKED_PTR") && !getenv("MI355LZ4_LINKED_POOL_BLOCKS") && !getenv("MI355LZ4_LINKED_RUNS") &&
                               !getenv("MI355LZ4_LINKED_RUNIN") && !getenv("MI355LZ4_LINKED_ASYNC");
-        if (linked && bigKiB > 0 && plainBig && !streamFirst && !splitOk && !deferEnd && lookBack >= 0 && !dict0 && c->decoder == 0 &&
-            !c->stats && c->linkedAsyncCap <= 0 && nBlocks >= 2 && nBlocks <= 512 && cu_auto(nBlocks, framedLen) &&
-            framedLen / (uint64_t)nBlocks >= (uint64_t)bigKiB * 1024u / 4u) {
+        bigEligible = linked && bigKiB > 0 && plainBig && !streamFirst && !splitOk && !deferEnd && lookBack >= 0 && !dict0 && c->decoder == 0 &&
+                      !c->stats && c->linkedAsyncCap <= 0 && nBlocks >= 2 && nBlocks <= 512 && cu_auto(nBlocks, framedLen);
+        if (bigEligible && framedLen / (uint64_t)nBlocks >= (uint64_t)bigKiB * 1024u / 2u) {
             const size_t metaBytes = 65536 + ((size_t)nBlocks * 2 + 4) * sizeof(uint32_t);
             if (dev_reserve(c->ptrBuf, (size_t)nBlocks * 65536u) == 0 && dev_reserve(c->tolMeta, metaBytes) == 0 &&
                 hipMemsetAsync(c->tolMeta.p, 0, metaBytes, c->stream) == hipSuccess) {
@@ -786,7 +788,21 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
     // MI355LZ4_LINKED_BIG = 0: never; = n: blocks from n KiB on (default 512: smaller blocks' ends still carry the wrong dictionary,
     // pass after pass).  Anything the form cannot take (a failing block, CU_REDO, snapshots that do not settle in BIG_PASSES)
     // leaves the call to the passes below: the results so far live in scratch.
-    if (bigPre) {
+    bool bigLate = false;
+    if (bigEligible && !bigPre && !a.asyncGate) {
+        const char *envBig = getenv("MI355LZ4_LINKED_BIG");
+        const long bigKiB = envBig ? atol(envBig) : 512;
+        const size_t metaBytes = 65536 + ((size_t)nBlocks * 2 + 4) * sizeof(uint32_t);
+        if ((uint64_t)stat[4] >= (uint64_t)bigKiB * 1024u && dev_reserve(c->ptrBuf, (size_t)nBlocks * 65536u) == 0 &&
+            dev_reserve(c->tolMeta, metaBytes) == 0 && hipMemsetAsync(c->tolMeta.p, 0, metaBytes, c->stream) == hipSuccess) {
+            uint8_t *meta = (uint8_t *)c->tolMeta.p;
+            a.zeroPage = meta; a.cuSnap = (uint8_t *)c->ptrBuf.p;
+            a.cuFlags = (uint32_t *)(meta + 65536); a.cuRes = (int32_t *)(meta + 65536 + ((size_t)nBlocks + 4) * sizeof(uint32_t));
+            bigLate = true;
+        }
+        (void)hipGetLastError();
+    }
+    if (bigPre || bigLate) {
         const char *envBig = getenv("MI355LZ4_LINKED_BIG");
         const long bigKiB = envBig ? atol(envBig) : 512;
         if (!a.asyncGate && (uint64_t)stat[4] >= (uint64_t)bigKiB * 1024u) {
@@ -796,7 +812,7 @@ static int decode_device(mi355lz4_ctx *c, const uint8_t *framed, uint64_t framed
             int passes = 0;
             for (int pass = 1; pass <= BIG_PASSES && !settled; pass++) {
                 a.cuPass = pass; passes = pass;
-                launch_cu_linked(a, pass > 1, c->stream);
+                launch_cu_linked(a, pass > 1 || bigLate, c->stream);
                 if (hipGetLastError() != hipSuccess) break;
                 if (pass == 1) continue;                                  // (every snapshot is new after the first pass)
                 BIG_TRY(hipMemcpyAsync(stat + 10, a.cuFlags, 8, hipMemcpyDeviceToHost, c->stream));

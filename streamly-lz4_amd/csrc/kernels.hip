@@ -605,20 +605,24 @@ __global__ __launch_bounds__(CU_THREADS) void k_decode_cu_linked(DecodeArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t lds[CU_LDS_BYTES];
     const int blk = (int)blockIdx.x;
     if (uni(a.result[blk]) >= 0) return;                                 // decoded on its own in the first pass: final
+    const uint8_t *dict = nullptr;
     if (blk == 0) {
-        // a first block that needs a dictionary: the call's (dict0) is not this path's; the block in front of the call is final, and
-        // the first launch has decoded this block against it
-        if (threadIdx.x == 0 && !(a.lookBack > 0 && a.cuRes[0] >= 65536)) atomicAdd(&a.cuFlags[1], 1u);
-        return;
+        // a first block that needs a dictionary: the call's own (dict0) is not this path's; the block in front of the call (a later
+        // group of a host call) is final, and this block is decoded against its end once -- by the first launch, or here in pass 1
+        const bool prevFinal = a.lookBack > 0 && uni(a.result[-1]) >= 65536;
+        if (prevFinal && uni(a.cuRes[0]) >= 65536) return;
+        if (!prevFinal || a.cuPass != 1) { if (threadIdx.x == 0) atomicAdd(&a.cuFlags[1], 1u); return; }
+        dict = a.out + a.outOff[-1] + (size_t)uni(a.result[-1]) - 65536u;
+    } else {
+        if (a.cuPass > 2 && uni(a.cuFlags[2 + blk - 1]) == 0u) return;  // the dictionary it was decoded against last time still stands
+        dict = a.cuPass == 1 ? a.zeroPage : a.cuSnap + (size_t)(blk - 1) * 65536u;
     }
-    if (a.cuPass > 2 && uni(a.cuFlags[2 + blk - 1]) == 0u) return;      // the dictionary it was decoded against last time still stands
     const uint8_t *data = nullptr;
     int compLen = 0, cap = 0;
     int r = uni(read_block_header(a, blk, data, compLen, cap));
     if (r == 0)
-        r = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), a.cuPass == 1 ? a.zeroPage : a.cuSnap + (size_t)(blk - 1) * 65536u,
-                                  65536u, a.framed, a.framed + a.framedLen, lds, nullptr, false,
-                                  (a.cuPass > 1 && uni(a.cuRes[blk]) >= 65536) ? uni(a.cuRes[blk]) : 0);      // (from the second pass on: stop where the bytes repeat the pass before)
+        r = decode_block_cu<true>(data, uni(compLen), a.out + a.outOff[blk], uni(cap), dict, 65536u, a.framed, a.framed + a.framedLen, lds, nullptr, false,
+                                  (blk > 0 && a.cuPass > 1 && uni(a.cuRes[blk]) >= 65536) ? uni(a.cuRes[blk]) : 0);      // (from the second pass on: stop where the bytes repeat the pass before)
     if (threadIdx.x == 0) {
         a.cuRes[blk] = r;
         if (r < 0 || (r < 65536 && blk + 1 < a.nBlocks)) atomicAdd(&a.cuFlags[1], 1u);      // an error, CU_REDO, or a block too short to be a whole dictionary
